@@ -1,0 +1,254 @@
+"""Pin the CPU oracle (oracle/) against outputs of the reference itself (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import (closed_form_state, grad_digest, load_golden, make_params, routing_case,
+                     synth_gtsdb_labels, synth_images, wave)
+from oracle import loss_fns as OL
+from oracle import models as OM
+
+T = torch.from_numpy
+FWD, GRAD = dict(rtol=2e-5, atol=2e-6), dict(rtol=2e-4, atol=2e-6)
+
+
+def close(a, b, rtol, atol):
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), rtol=rtol, atol=atol)
+
+
+def test_squash_golden_and_known_answer():
+    g = load_golden('squash')
+    out = OM.squash(T(g['v']))
+    close(out.numpy(), g['out'], **FWD)
+    close(out[0, 0, :2].numpy(), [0.5769231, 0.7692307], 1e-6, 1e-7)
+    assert torch.isnan(OM.squash(torch.zeros(1, 4))).all()        # no epsilon
+
+
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+@pytest.mark.parametrize('n_iter', [1, 3, 5])
+def test_routing_golden(ci, n_iter):
+    g = load_golden('routing')
+    R, N, C, Din, Dout = (int(v) for v in g['c%d_shape' % ci])
+    u, W, G = routing_case(ci, R, N, C, Din, Dout)
+    ut, Wt = T(u).clone().requires_grad_(True), T(W).clone().requires_grad_(True)
+    v = OM.dynamic_routing(ut, Wt, n_iter)
+    (v * T(G)).sum().backward()
+    key = 'c%d_r%d_' % (ci, n_iter)
+    close(v.detach().numpy(), g[key + 'v'], **FWD)
+    close(ut.grad.numpy(), g[key + 'du'], **GRAD)
+    close(grad_digest(Wt.grad), g[key + 'dW_digest'], 2e-4, 1e-5)
+    if ci == 0:
+        close(Wt.grad.numpy(), g[key + 'dW'], **GRAD)
+
+
+def test_routing_singleton_is_iteration_independent():
+    u, W, _ = routing_case(0, 3, 32, 1, 8, 5)
+    outs = [OM.dynamic_routing(T(u), T(W), r) for r in (1, 3, 5)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_cell_gather_golden():
+    g = load_golden('cell_gather')
+    gg, B = int(g['g']), int(g['B'])
+    feat = wave((B, 256, 4 * gg, 4 * gg), float(g['feat_phase']), freq=float(g['feat_freq']))
+    u = OM.cell_gather(T(feat), gg)
+    assert np.array_equal(u.numpy(), g['u'])
+
+
+def test_losses_golden():
+    g = load_golden('losses')
+    r, phi = OL.polar_transform(T(g['polar_in']))
+    close(r.numpy(), g['polar_r'], **FWD)
+    close(phi.numpy(), g['polar_phi'], **FWD)
+    close(phi[0].numpy(), [0.8090171, 0.25, 0.6224747, 0.3658814, 0.2658284], 1e-5, 1e-6)
+
+    p = make_params(recon=False)
+    ct = T(g['dc_caps']).clone().requires_grad_(True)
+    l = OL.darkcapsule_loss(ct, T(g['dc_y']), p)
+    l.backward()
+    close(l.item(), g['dc_loss'], **FWD)
+    close(ct.grad.numpy(), g['dc_dcaps'], **GRAD)
+
+    B, gg = g['dc_caps'].shape[0], g['dc_caps'].shape[1]
+    c3 = T(wave((B, gg, gg, 43, 21), 0.8, amp=0.3, freq=0.377)).requires_grad_(True)
+    l3 = OL.darkcapsule3_loss(c3, T(g['dc_y']), p)
+    l3.backward()
+    close(l3.item(), g['dc3_loss'], **FWD)
+    close(grad_digest(c3.grad), g['dc3_dcaps_digest'], 2e-4, 1e-5)
+    c2 = T(wave((B, gg, gg, 48), 1.8, amp=0.3, freq=0.477)).requires_grad_(True)
+    l2 = OL.darkcapsule2_loss(c2, T(g['dc_y']), p)
+    l2.backward()
+    close(l2.item(), g['dc2_loss'], **FWD)
+    close(c2.grad.numpy(), g['dc2_dcaps'], **GRAD)
+
+    pk = make_params(n_classes=3, recon=False)
+    known = OL.capsule_loss(torch.full((2, 3), 0.5), torch.tensor([0, 2]), pk).item()
+    close(known, 0.32, 1e-6, 1e-7)
+    close(known, g['cap_known'], 1e-6, 1e-7)
+    xim = T(wave((5, 3, 32, 32), 0.1, amp=0.9, freq=0.211))
+    for recon in (False, True):
+        pc = make_params(recon=recon)
+        st = T(g['cap_scores']).clone().requires_grad_(True)
+        rt = T(wave((5, 3, 32, 32), 2.1, amp=0.9, freq=0.173)).requires_grad_(True)
+        l = OL.capsule_loss(st, T(g['cap_y']), pc, xim, rt)
+        l.backward()
+        tag = 'cap_recon%d_' % int(recon)
+        close(l.item(), g[tag + 'loss'], **FWD)
+        close(st.grad.numpy(), g[tag + 'dscores'], **GRAD)
+        if recon:
+            close(grad_digest(rt.grad), g[tag + 'drecon_digest'], 2e-4, 1e-6)
+
+    sct = T(g['cnn_scores']).clone().requires_grad_(True)
+    lc = OL.cnn_loss(sct, T(g['cap_y'][:4]))
+    lc.backward()
+    close(lc.item(), g['cnn_loss'], **FWD)
+    close(sct.grad.numpy(), g['cnn_dscores'], **GRAD)
+    close(g['cnn_zero'], np.log(3.0), 1e-6, 1e-7)
+
+
+@pytest.mark.parametrize('tag', ['dk_d', 'dk_r'])
+def test_dark_loss_golden(tag):
+    g = load_golden('losses')
+    nb, C, inp, gd = (int(v) for v in g[tag + '_cfg'])
+    p = make_params(n_boxes=nb, n_classes=C, darknet_input=inp, n_grid=gd)
+    pt = T(g[tag + '_pred']).clone().requires_grad_(True)
+    loss, avg_iou = OL.dark_loss(pt, T(g[tag + '_y']), p)
+    loss.backward()
+    close(loss.item(), g[tag + '_loss'], **FWD)
+    close(avg_iou.item(), g[tag + '_avg_iou'], **FWD)
+    close(pt.grad.numpy(), g[tag + '_dpred'], **GRAD)
+
+
+def test_iou_and_cwh_known_answers():
+    g = load_golden('losses')
+    iou = OL.iou_xyxy(torch.tensor([[[0., 0, 2, 2], [1, 1, 3, 3]]]), torch.tensor([[[0., 0, 2, 2]]]))
+    close(iou.numpy(), [[1.0, 1.0 / 7.0]], 1e-6, 1e-7)
+    close(iou.numpy(), g['iou_known'], 1e-6, 1e-7)
+    xy = OL.cwh_to_xyxy(torch.tensor([[[.5, .5, .25, .5]]]), 416, 13)
+    close(xy.numpy(), [[[-36, -88, 68, 120]]], 1e-6, 1e-5)
+    close(xy.numpy(), g['cwh_known'], 1e-6, 1e-5)
+
+
+# ----------------------------------------------------------------------------- whole models
+def _check_model(tag, net, forward, steps=0, lr=1e-3, grad_tol=2e-3):
+    g = load_golden('models')
+    net.load_state_dict(closed_form_state(net))
+    net.train()
+    out, loss = forward(net)
+    loss.backward()
+    first = out[0] if isinstance(out, tuple) else out
+    close(first.detach().numpy(), g[tag + '_out'], 1e-4, 1e-5)
+    close(loss.item(), g[tag + '_loss'], 1e-4, 1e-6)
+    if isinstance(out, tuple):
+        close(grad_digest(out[1]), g[tag + '_recon_digest'], 1e-3, 1e-5)
+    n_checked = 0
+    for name, p in net.named_parameters():
+        key = '%s_grad/%s' % (tag, name)
+        if p.grad is None:
+            assert key not in g.files
+            continue
+        # conv biases that feed a BatchNorm have analytically-zero, noise-only gradients
+        if '.conv_' in name and name.endswith('bias'):
+            continue
+        ref = g[key]
+        scale = max(1e-6, float(np.abs(ref[2:]).max()))
+        close(grad_digest(p.grad), ref, grad_tol, grad_tol * scale)
+        n_checked += 1
+    assert n_checked > 0
+    for name, b in net.named_buffers():
+        if name.endswith('running_mean') or name.endswith('running_var'):
+            close(b.numpy(), g['%s_buf/%s' % (tag, name)], 1e-4, 1e-6)
+    if steps:
+        net.load_state_dict(closed_form_state(net))
+        opt = torch.optim.Adam([p for p in net.parameters() if p.requires_grad], lr=lr)
+        curve = []
+        for _ in range(steps):
+            out, loss = forward(net)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            curve.append(loss.item())
+        close(curve, g[tag + '_curve'], 2e-3, 1e-5)
+
+
+def test_capsule_net_golden():
+    x = T(synth_images(4, 32, seed=21))
+    y = T(np.array([3, 42, 0, 17], dtype=np.int64))
+    p = make_params(model='capsule', recon=True)
+
+    def fwd(net):
+        scores, rec = net(x, y, True)
+        return (scores, rec), OL.capsule_loss(scores, y, p, x, rec)
+    _check_model('capsule_recon', OM.CapsuleNet(p), fwd, steps=12)
+    p0 = make_params(model='capsule', recon=False)
+
+    def fwd0(net):
+        scores = net(x)
+        return scores, OL.capsule_loss(scores, y, p0)
+    _check_model('capsule', OM.CapsuleNet(p0), fwd0)
+
+
+def test_darkcapsule_net_golden():
+    p = make_params(model='darkcapsule', n_grid=2, darknet_input=64, recon=False)
+    x = T(synth_images(4, 64, seed=22))
+    y = T(synth_gtsdb_labels(4, 2, 43, seed=23))
+
+    def fwd(net):
+        out = net(x)
+        return out, OL.darkcapsule_loss(out, y, p)
+    _check_model('darkcapsule', OM.DarkCapsuleNet(p), fwd, steps=20)
+    net = OM.DarkCapsuleNet(p)
+    net.load_state_dict(closed_form_state(net))
+    net.eval()
+    with torch.no_grad():
+        close(net(x).numpy(), load_golden('models')['darkcapsule_eval_out'], 1e-4, 1e-5)
+
+
+def test_darkcapsule3_net_golden():
+    p = make_params(model='darkcapsule3', n_grid=2, n_classes=3, recon=False)
+    x = T(synth_images(4, 64, seed=22))[:2]
+    y = T(synth_gtsdb_labels(2, 2, 3, seed=24))
+
+    def fwd(net):
+        out = net(x)
+        return out, OL.darkcapsule3_loss(out, y, p)
+    _check_model('darkcapsule3', OM.DarkCapsuleNet3(p), fwd)
+
+
+@pytest.mark.parametrize('tag,nb,C', [('darknet_d', 2, 0), ('darknet_r', 1, 3)])
+def test_darknet_golden(tag, nb, C):
+    p = make_params(model=tag, n_grid=2, n_boxes=nb, n_classes=C, darknet_input=64, dropout=0.0)
+    x = T(synth_images(4, 64, seed=22))[:2]
+    y = T(synth_gtsdb_labels(2, 2, C, seed=25 + nb))
+
+    def fwd(net):
+        out = net(x)
+        return out, OL.dark_loss(out, y, p)[0]
+    _check_model(tag, OM.DarkNet(p), fwd, steps=6, grad_tol=5e-3)
+
+
+def test_convnet_golden():
+    p = make_params(model='cnn', dropout=0.0)
+    x = T(synth_images(4, 32, seed=21))
+    y = T(np.array([3, 42, 0, 17], dtype=np.int64))
+
+    def fwd(net):
+        out = net(x)
+        return out, OL.cnn_loss(out, y)
+    _check_model('cnn', OM.ConvNet(p), fwd)
+
+
+def test_state_dict_keys_match_reference_names():
+    p = make_params()
+    keys = set(OM.DarkCapsuleNet(p).state_dict())
+    for k in ('conv.conv_1.weight', 'conv.conv_1.bias', 'conv.bn_5.running_var',
+              'traffic_sign_capsules.route_weights', 'decoder.0.weight', 'decoder.12.bias'):
+        assert k in keys
+    keys = set(OM.CapsuleNet(p).state_dict())
+    for k in ('conv1.weight', 'primary_capsules.capsules.7.bias', 'traffic_sign_capsules.route_weights',
+              'decoder.4.weight'):
+        assert k in keys
+    keys = set(OM.DarkNet(make_params(n_boxes=2, n_classes=0)).state_dict())
+    for k in ('model.conv_1.weight', 'model.bn_18.running_mean', 'model.conv_19.weight'):
+        assert k in keys
+    assert 'model.conv_1.bias' not in keys
