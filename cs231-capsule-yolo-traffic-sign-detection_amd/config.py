@@ -1,0 +1,15 @@
+"""Constants with the reference's names (config.py:1-52)."""
+model_names = ['cnn', 'capsule', 'darknet_d', 'darknet_r', 'darkcapsule']
+
+GTSRB = 'data/GTSRB'
+GTSDB = 'data/GTSDB'
+
+tr_d, ev_d, te_d = '/train.p', '/eval.p', '/test.p'
+tr_sm_d, ev_sm_d, te_sm_d = '/train_small.p', '/eval_small.p', '/test_small.p'
+
+data_dir = {'cnn': GTSRB, 'capsule': GTSRB, 'darknet_d': GTSDB, 'darknet_r': GTSDB, 'darkcapsule': GTSDB}
+model_dir = {name: 'experiments/' + name for name in model_names}
+input_shape = {'cnn': (3, 32, 32), 'capsule': (3, 32, 32), 'darknet_d': (3, 224, 224), 'darknet_r': (3, 224, 224),
+               'darkcapsule': (3, 224, 224)}
+
+max_metric_samples = 1000

@@ -1,0 +1,43 @@
+// torch.optim.Adam step (main.py:72,280) for a whole list of tensors in one launch (gfx950).
+// table[k] = {param*, grad*, exp_avg*, exp_avg_sq*, numel}; blockmap[b] = {tensor, chunk}.
+// Same update order as torch's single-tensor path: m, v, denom = sqrt(v)/sqrt(bc2) + eps,
+// p -= (lr/bc1) * m / denom.  HBM-bound: 4 reads + 3 writes of 4 B per element.
+#include "common.h"
+
+namespace {
+
+struct AdamEntry {
+  float* p; const float* g; float* m; float* v; long long n;
+};
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __restrict__ table, const int2* __restrict__ blockmap,
+                                                         int chunk, float step_size, float beta1, float beta2, float eps,
+                                                         float inv_bc2_sqrt) {
+  const int2 bm = blockmap[blockIdx.x];
+  const AdamEntry e = table[bm.x];
+  const long long begin = (long long)bm.y * chunk;
+  long long end = begin + chunk;
+  if (end > e.n) end = e.n;
+  for (long long i = begin + threadIdx.x; i < end; i += 256) {
+    const float g = e.g[i];
+    const float m = beta1 * e.m[i] + (1.f - beta1) * g;
+    const float v = beta2 * e.v[i] + (1.f - beta2) * g * g;
+    e.m[i] = m;
+    e.v[i] = v;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    e.p[i] -= step_size * (m / denom);
+  }
+}
+
+}  // namespace
+
+extern "C" int cy_adam_multi(const void* table, const void* blockmap, int n_blocks, int chunk, float lr, float beta1,
+                             float beta2, float eps, float bias_corr1, float bias_corr2, void* stream) {
+  CY_REQUIRE(table && blockmap && n_blocks > 0 && chunk > 0, "cy_adam_multi: bad arguments");
+  CY_REQUIRE(bias_corr1 > 0.f && bias_corr2 > 0.f, "cy_adam_multi: bias corrections must be positive");
+  adam_multi_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>((const AdamEntry*)table, (const int2*)blockmap, chunk,
+                                                               lr / bias_corr1, beta1, beta2, eps,
+                                                               1.f / sqrtf(bias_corr2));
+  CY_LAUNCH_CHECK("cy_adam_multi");
+  return 0;
+}

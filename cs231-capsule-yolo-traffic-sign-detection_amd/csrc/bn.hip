@@ -1,0 +1,246 @@
+// BatchNorm2d (+LeakyReLU) on NHWC activations, training and eval mode, forward and backward.
+// Replaces nn.BatchNorm2d / nn.LeakyReLU of models.py:132-223, 347-365.  HBM-bound streaming
+// kernels: 16-byte accesses, one pass per tensor.  The batch statistics themselves come out of the
+// convolution epilogue (conv.hip) as double sum / sum-of-squares.
+#include "common.h"
+
+namespace {
+
+__global__ void bn_finalize_kernel(const double* __restrict__ stats, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* running_mean, float* running_var,
+                                   float momentum, float eps, float* scale, float* shift, float* mean,
+                                   float* invstd, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const double m = stats[2 * n] / count;
+  double var = stats[2 * n + 1] / count - m * m;           // biased variance normalises the batch
+  if (var < 0.0) var = 0.0;
+  const float is = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[n] * is;
+  mean[n] = (float)m;
+  invstd[n] = is;
+  scale[n] = sc;
+  shift[n] = beta[n] - (float)m * sc;
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)m;
+    running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unbiased;
+  }
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, float* scale,
+                               float* shift, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const float sc = gamma[n] / sqrtf(rv[n] + eps);
+  scale[n] = sc;
+  shift[n] = beta[n] - rm[n] * sc;
+}
+
+__device__ __forceinline__ float lrelu(float y, float slope) { return y > 0.f ? y : y * slope; }
+
+// A = lrelu(Z*scale + shift); float4 path when N % 4 == 0
+template <bool AFFINE>
+__global__ void affine_act_kernel(const float* __restrict__ Z, float* __restrict__ A, const float* __restrict__ scale,
+                                  const float* __restrict__ shift, float slope, long long n4, int N) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 z = ((const float4*)Z)[i];
+    if (AFFINE) {
+      const int c = (int)((i * 4) % N);
+      const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+      z.x = z.x * sc.x + sh.x; z.y = z.y * sc.y + sh.y; z.z = z.z * sc.z + sh.z; z.w = z.w * sc.w + sh.w;
+    }
+    z.x = lrelu(z.x, slope); z.y = lrelu(z.y, slope); z.z = lrelu(z.z, slope); z.w = lrelu(z.w, slope);
+    ((float4*)A)[i] = z;
+  }
+}
+__global__ void affine_act_scalar_kernel(const float* __restrict__ Z, float* __restrict__ A,
+                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                         float slope, long long n, int N) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float z = Z[i];
+    if (scale != nullptr) { const int c = (int)(i % N); z = z * scale[c] + shift[c]; }
+    A[i] = lrelu(z, slope);
+  }
+}
+
+// pass 1 of the backward: per-channel sums of dYhat and dYhat*xhat.
+// Thread -> 4 channels (float4) of one row; LPR = N/4 lanes per row, 256/LPR rows in parallel.
+__global__ void bn_bwd_reduce_kernel(const float* __restrict__ Z, const float* __restrict__ dA,
+                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                     const float* __restrict__ mean, const float* __restrict__ invstd, float slope,
+                                     double* red, long long P, int N, long long rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [256][8]
+  const int LPR = N >> 2;
+  const int rpar = 256 / LPR;
+  const int t = threadIdx.x;
+  const int u = t % LPR, rsub = t / LPR;
+  const int c = u * 4;
+  const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+  const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > P) r1 = P;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  for (long long r = r0 + rsub; r < r1; r += rpar) {
+    const float4 z = *(const float4*)(Z + r * N + c);
+    const float4 g = *(const float4*)(dA + r * N + c);
+#define CY_ACC(f)                                                   \
+    {                                                               \
+      const float y = z.f * sc.f + sh.f;                            \
+      const float d = y > 0.f ? g.f : g.f * slope;                  \
+      s1.f += d;                                                    \
+      s2.f += d * ((z.f - mu.f) * is.f);                            \
+    }
+    CY_ACC(x) CY_ACC(y) CY_ACC(z) CY_ACC(w)
+#undef CY_ACC
+  }
+  float* my = sm + t * 8;
+  my[0] = s1.x; my[1] = s1.y; my[2] = s1.z; my[3] = s1.w;
+  my[4] = s2.x; my[5] = s2.y; my[6] = s2.z; my[7] = s2.w;
+  __syncthreads();
+  // thread t < 2*N handles (channel n = t % N, which = t / N)
+  for (int idx = t; idx < 2 * N; idx += 256) {
+    const int n = idx % N, which = idx / N;
+    const int uu = n >> 2, e = n & 3;
+    double acc = 0.0;
+    for (int rs = 0; rs < rpar; ++rs) acc += (double)sm[(rs * LPR + uu) * 8 + which * 4 + e];
+    atomicAdd(red + 2 * n + which, acc);
+  }
+}
+
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ dA, float* __restrict__ dZ,
+                                    const float* __restrict__ scale, const float* __restrict__ shift,
+                                    const float* __restrict__ mean, const float* __restrict__ invstd, float slope,
+                                    const double* __restrict__ red, double inv_count, long long n4, int N) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    const int c = (int)((i * 4) % N);
+    const float4 z = ((const float4*)Z)[i], g = ((const float4*)dA)[i];
+    const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+    float4 o;
+#define CY_APPLY(f, k)                                                       \
+    {                                                                        \
+      const float y = z.f * sc.f + sh.f;                                     \
+      const float d = y > 0.f ? g.f : g.f * slope;                           \
+      const float xh = (z.f - mu.f) * is.f;                                  \
+      const float m1 = (float)(red[2 * (c + k)] * inv_count);                \
+      const float m2 = (float)(red[2 * (c + k) + 1] * inv_count);            \
+      o.f = sc.f * (d - m1 - xh * m2);                                       \
+    }
+    CY_APPLY(x, 0) CY_APPLY(y, 1) CY_APPLY(z, 2) CY_APPLY(w, 3)
+#undef CY_APPLY
+    ((float4*)dZ)[i] = o;
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ red, float* dgamma, float* dbeta, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  dbeta[n] = (float)red[2 * n];
+  dgamma[n] = (float)red[2 * n + 1];
+}
+
+__global__ void act_bwd_kernel(const float* __restrict__ Z, const float* __restrict__ dA, float* __restrict__ dZ,
+                               float slope, long long n) {
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float g = dA[i];
+    dZ[i] = Z[i] > 0.f ? g : g * slope;
+  }
+}
+
+inline unsigned stream_grid(long long work_items) {
+  long long b = cy_ceil_div(work_items, 256);
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+inline bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+
+}  // namespace
+
+extern "C" int cy_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, float momentum, float eps, float* scale,
+                              float* shift, float* mean, float* invstd, int N, void* stream) {
+  CY_REQUIRE(stats && gamma && beta && scale && shift && mean && invstd && N > 0 && count > 0,
+             "cy_bn_finalize: bad arguments");
+  CY_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "cy_bn_finalize: running stats must come in pairs");
+  bn_finalize_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(stats, (double)count, gamma, beta, running_mean,
+                                                                       running_var, momentum, eps, scale, shift, mean,
+                                                                       invstd, N);
+  CY_LAUNCH_CHECK("cy_bn_finalize");
+  return 0;
+}
+
+extern "C" int cy_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, float eps, float* scale, float* shift, int N,
+                                      void* stream) {
+  CY_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && N > 0, "cy_bn_eval_scale_shift: bad arguments");
+  bn_eval_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(gamma, beta, running_mean, running_var, eps, scale,
+                                                                   shift, N);
+  CY_LAUNCH_CHECK("cy_bn_eval_scale_shift");
+  return 0;
+}
+
+extern "C" int cy_affine_act(const float* Z, float* A, const float* scale, const float* shift, float slope,
+                             long long P, int N, void* stream) {
+  CY_REQUIRE(Z && A && P > 0 && N > 0, "cy_affine_act: bad arguments");
+  CY_REQUIRE((scale == nullptr) == (shift == nullptr), "cy_affine_act: scale/shift must come in pairs");
+  hipStream_t s = (hipStream_t)stream;
+  const long long n = P * N;
+  const bool v4 = (N % 4 == 0) && (((uintptr_t)Z & 15) == 0) && (((uintptr_t)A & 15) == 0);
+  if (v4 && scale) affine_act_kernel<true><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  else if (v4) affine_act_kernel<false><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  else affine_act_scalar_kernel<<<stream_grid(n), 256, 0, s>>>(Z, A, scale, shift, slope, n, N);
+  CY_LAUNCH_CHECK("cy_affine_act");
+  return 0;
+}
+
+extern "C" int cy_bn_bwd_reduce(const float* Z, const float* dA, const float* scale, const float* shift,
+                                const float* mean, const float* invstd, float slope, double* red, long long P, int N,
+                                void* stream) {
+  CY_REQUIRE(Z && dA && scale && shift && mean && invstd && red && P > 0, "cy_bn_bwd_reduce: bad arguments");
+  CY_REQUIRE(N % 4 == 0 && pow2(N / 4) && N / 4 <= 256, "cy_bn_bwd_reduce: N=%d must be 4*2^k <= 1024", N);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(red, 0, (size_t)N * 2 * sizeof(double), s);
+  if (e != hipSuccess) return cy_set_error((int)e, "cy_bn_bwd_reduce: memset: %s", hipGetErrorString(e));
+  const int rpar = 256 / (N / 4);
+  long long rows_per_block = cy_ceil_div(P, 2048);
+  if (rows_per_block < 4 * rpar) rows_per_block = 4 * rpar;
+  rows_per_block = cy_ceil_div(rows_per_block, rpar) * rpar;
+  const long long blocks = cy_ceil_div(P, rows_per_block);
+  bn_bwd_reduce_kernel<<<(unsigned)blocks, 256, 256 * 8 * 4, s>>>(Z, dA, scale, shift, mean, invstd, slope, red, P, N,
+                                                                 rows_per_block);
+  CY_LAUNCH_CHECK("cy_bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int cy_bn_bwd_apply(const float* Z, const float* dA, float* dZ, const float* scale, const float* shift,
+                               const float* mean, const float* invstd, const float* gamma, float slope,
+                               const double* red, float* dgamma, float* dbeta, long long P, int N, void* stream) {
+  CY_REQUIRE(Z && dA && dZ && scale && shift && mean && invstd && red && P > 0, "cy_bn_bwd_apply: bad arguments");
+  CY_REQUIRE(N % 4 == 0, "cy_bn_bwd_apply: N=%d must be a multiple of 4", N);
+  (void)gamma;
+  hipStream_t s = (hipStream_t)stream;
+  const long long n4 = P * N / 4;
+  bn_bwd_apply_kernel<<<stream_grid(n4), 256, 0, s>>>(Z, dA, dZ, scale, shift, mean, invstd, slope, red,
+                                                      1.0 / (double)P, n4, N);
+  CY_LAUNCH_CHECK("cy_bn_bwd_apply");
+  if (dgamma && dbeta) {
+    bn_param_grad_kernel<<<(N + 255) / 256, 256, 0, s>>>(red, dgamma, dbeta, N);
+    CY_LAUNCH_CHECK("cy_bn_bwd_apply(param)");
+  }
+  return 0;
+}
+
+extern "C" int cy_act_bwd(const float* Z, const float* dA, float* dZ, float slope, long long n, void* stream) {
+  CY_REQUIRE(Z && dA && dZ && n > 0, "cy_act_bwd: bad arguments");
+  act_bwd_kernel<<<stream_grid(n), 256, 0, (hipStream_t)stream>>>(Z, dA, dZ, slope, n);
+  CY_LAUNCH_CHECK("cy_act_bwd");
+  return 0;
+}

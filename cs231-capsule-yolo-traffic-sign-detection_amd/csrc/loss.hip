@@ -1,0 +1,206 @@
+// Loss kernels: forward value and input gradient in one launch each (gfx950).
+// Replaces loss_fns.py:11-23 (capsule_loss), 60-142 (dark_loss, dense form), 187-204
+// (darkcapsule_loss) with utils.py:69-85 (polar_transform) and utils.py:353-371 (cwh_to_xy_torch).
+// All of them touch a few thousand cells: one 1024-thread block, fixed summation order
+// (bitwise reproducible loss curves), no atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int LT = 1024;
+
+// block-wide sum; result valid in thread 0
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int t = threadIdx.x;
+  if ((t & 63) == 0) red[t >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (t == 0)
+    for (int k = 0; k < (int)(blockDim.x >> 6); ++k) s += red[k];
+  __syncthreads();
+  return s;
+}
+
+__device__ __forceinline__ float relu(float x) { return x > 0.f ? x : 0.f; }
+
+// ---- darkcapsule_loss ---------------------------------------------------------------------------
+__global__ __launch_bounds__(LT) void darkcapsule_loss_kernel(const float* __restrict__ caps, const double* __restrict__ y,
+                                                              int ystride, float* loss_out, float* __restrict__ dcaps,
+                                                              int ncells, float invB) {
+  __shared__ float red[LT / 64];
+  const float PI = 3.14159265358979323846f;               // np.pi rounded to fp32, as torch does for tensor*float
+  float local = 0.f;
+  for (int cell = threadIdx.x; cell < ncells; cell += LT) {
+    const double* yc = y + (long long)cell * ystride;
+    const float yr = (float)yc[0], yx = (float)yc[1], yy = (float)yc[2], yw = (float)yc[3], yh = (float)yc[4];
+    const float a1 = yx * PI, a2 = yy * PI, a3 = yh * PI, a4 = yw * PI * 2.f;
+    const float s1 = sinf(a1), s2 = sinf(a2), s3 = sinf(a3), s4 = sinf(a4);
+    const float c2 = cosf(a2), c3 = cosf(a3), c4 = cosf(a4);
+    const float phi[5] = {s1, s1 * c2, s1 * s2 * c3, s1 * s2 * s3 * c4, s1 * s2 * s3 * s4};
+    float c[5], n2 = 0.f, coord = 0.f;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) { c[k] = caps[(long long)cell * 5 + k]; n2 += c[k] * c[k]; coord += c[k] * phi[k]; }
+    const float r = sqrtf(n2);
+    const float left = relu(0.9f - r), right = relu(r - 0.1f);
+    local += yr * left * left + 0.5f * (1.f - yr) * right * right - coord;
+    const float dr = -2.f * yr * left + (1.f - yr) * right;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) dcaps[(long long)cell * 5 + k] = (dr * c[k] / r - phi[k]) * invB;
+  }
+  const float s = block_sum(local, red);
+  if (threadIdx.x == 0) *loss_out = s * invB;
+}
+
+// ---- capsule margin loss -------------------------------------------------------------------------
+__global__ __launch_bounds__(LT) void margin_loss_kernel(const float* __restrict__ scores, const long long* __restrict__ y,
+                                                         float* loss_out, float* __restrict__ dscores, int B, int C) {
+  __shared__ float red[LT / 64];
+  float local = 0.f;
+  const float invB = 1.f / (float)B;
+  for (int idx = threadIdx.x; idx < B * C; idx += LT) {
+    const int b = idx / C, c = idx - b * C;
+    const float lab = (y[b] == (long long)c) ? 1.f : 0.f;
+    const float r = scores[idx];
+    const float left = relu(0.9f - r), right = relu(r - 0.1f);
+    local += lab * left * left + 0.5f * (1.f - lab) * right * right;
+    dscores[idx] = (-2.f * lab * left + (1.f - lab) * right) * invB;
+  }
+  const float s = block_sum(local, red);
+  if (threadIdx.x == 0) *loss_out = s * invB;
+}
+
+// loss_out += coef_over_B * sum (x - recon)^2 ; drecon = -2 coef_over_B (x - recon)
+__global__ __launch_bounds__(LT) void recon_loss_kernel(const float* __restrict__ x, const float* __restrict__ recon,
+                                                        float coef_over_B, float* loss_out, float* __restrict__ drecon,
+                                                        long long n) {
+  __shared__ float red[LT / 64];
+  float local = 0.f;
+  for (long long i = threadIdx.x; i < n; i += LT) {
+    const float d = x[i] - recon[i];
+    local += d * d;
+    drecon[i] = -2.f * coef_over_B * d;
+  }
+  const float s = block_sum(local, red);
+  if (threadIdx.x == 0) *loss_out += s * coef_over_B;
+}
+
+// ---- dark_loss (YOLOv1), dense masked form ----------------------------------------------------------
+constexpr int MAXNB = 4;
+__global__ __launch_bounds__(LT) void dark_loss_kernel(const float* __restrict__ yp, const double* __restrict__ yt,
+                                                       float* loss_out, float* avg_iou_out, float* __restrict__ dpred,
+                                                       int ncells, int nb, int C, float l_coord, float l_noobj,
+                                                       float img, float cell_px, float invB) {
+  __shared__ float red[LT / 64];
+  const int PS = 5 * nb + C, TS = 5 + C;
+  float local = 0.f, iou_sum = 0.f, nobj = 0.f;
+  for (int cell = threadIdx.x; cell < ncells; cell += LT) {
+    const float* p = yp + (long long)cell * PS;
+    const double* tr = yt + (long long)cell * TS;
+    float* dp = dpred + (long long)cell * PS;
+    const float t0 = (float)tr[0];
+    for (int k = 0; k < PS; ++k) dp[k] = 0.f;
+    if (t0 == 0.f) {                                        // no-object cell: confidence of every box -> 0
+      for (int b = 0; b < nb; ++b) {
+        const float pc = p[5 * b];
+        local += l_noobj * pc * pc;
+        dp[5 * b] = 2.f * l_noobj * pc * invB;
+      }
+    } else if (t0 == 1.f) {
+      const float tx = (float)tr[1], ty = (float)tr[2], tw = (float)tr[3], th = (float)tr[4];
+      const float tx1 = tx * cell_px - tw * img / 2, ty1 = ty * cell_px - th * img / 2;
+      const float tx2 = tx * cell_px + tw * img / 2, ty2 = ty * cell_px + th * img / 2;
+      const float tarea = (tx2 - tx1) * (ty2 - ty1);
+      float best = -INFINITY;
+      int bi = 0;
+      for (int b = 0; b < nb; ++b) {
+        const float x = p[5 * b + 1], yv = p[5 * b + 2], w = p[5 * b + 3], h = p[5 * b + 4];
+        const float x1 = x * cell_px - w * img / 2, y1 = yv * cell_px - h * img / 2;
+        const float x2 = x * cell_px + w * img / 2, y2 = yv * cell_px + h * img / 2;
+        const float iw = fmaxf(fminf(x2, tx2) - fmaxf(x1, tx1), 0.f), ih = fmaxf(fminf(y2, ty2) - fmaxf(y1, ty1), 0.f);
+        const float inter = iw * ih;
+        const float iou = inter / ((x2 - x1) * (y2 - y1) + tarea - inter);
+        if (iou > best) { best = iou; bi = b; }              // first maximum wins, like torch.max
+      }
+      iou_sum += best; nobj += 1.f;
+      for (int b = 0; b < nb; ++b) {
+        const float pc = p[5 * b];
+        if (b != bi) {                                       // not responsible: treated as no-object confidence
+          local += l_noobj * pc * pc;
+          dp[5 * b] = 2.f * l_noobj * pc * invB;
+        } else {
+          const float x = p[5 * b + 1], yv = p[5 * b + 2], w = p[5 * b + 3], h = p[5 * b + 4];
+          const float sw = sqrtf(w), sh = sqrtf(h), stw = sqrtf(tw), sth = sqrtf(th);
+          local += (pc - best) * (pc - best) + l_coord * ((x - tx) * (x - tx) + (yv - ty) * (yv - ty)) +
+                   l_coord * ((sw - stw) * (sw - stw) + (sh - sth) * (sh - sth));
+          dp[5 * b] = 2.f * (pc - best) * invB;              // IoU is detached (utils.py:370)
+          dp[5 * b + 1] = 2.f * l_coord * (x - tx) * invB;
+          dp[5 * b + 2] = 2.f * l_coord * (yv - ty) * invB;
+          dp[5 * b + 3] = l_coord * (sw - stw) / sw * invB;
+          dp[5 * b + 4] = l_coord * (sh - sth) / sh * invB;
+        }
+      }
+      for (int k = 0; k < C; ++k) {
+        const float d = p[5 * nb + k] - (float)tr[5 + k];
+        local += d * d;
+        dp[5 * nb + k] = 2.f * d * invB;
+      }
+    }
+  }
+  const float s = block_sum(local, red);
+  const float si = block_sum(iou_sum, red);
+  const float sn = block_sum(nobj, red);
+  if (threadIdx.x == 0) { *loss_out = s * invB; *avg_iou_out = si / sn; }
+}
+
+__global__ void scale_by_scalar_kernel(const float* __restrict__ in, const float* __restrict__ scalar,
+                                       float* __restrict__ out, long long n) {
+  const float k = *scalar;
+  const long long stride = (long long)gridDim.x * blockDim.x;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = in[i] * k;
+}
+
+}  // namespace
+
+extern "C" int cy_darkcapsule_loss(const float* caps, const double* y, int ystride, float* loss_out, float* dcaps,
+                                   int B, int cells, void* stream) {
+  CY_REQUIRE(caps && y && loss_out && dcaps && B > 0 && cells > 0 && ystride >= 5, "cy_darkcapsule_loss: bad arguments");
+  darkcapsule_loss_kernel<<<1, LT, 0, (hipStream_t)stream>>>(caps, y, ystride, loss_out, dcaps, B * cells, 1.f / (float)B);
+  CY_LAUNCH_CHECK("cy_darkcapsule_loss");
+  return 0;
+}
+
+extern "C" int cy_margin_loss(const float* scores, const long long* y, float* loss_out, float* dscores, int B, int C,
+                              void* stream) {
+  CY_REQUIRE(scores && y && loss_out && dscores && B > 0 && C > 0, "cy_margin_loss: bad arguments");
+  margin_loss_kernel<<<1, LT, 0, (hipStream_t)stream>>>(scores, y, loss_out, dscores, B, C);
+  CY_LAUNCH_CHECK("cy_margin_loss");
+  return 0;
+}
+
+extern "C" int cy_recon_loss_add(const float* x, const float* recon, float coef_over_B, float* loss_out, float* drecon,
+                                 long long n, void* stream) {
+  CY_REQUIRE(x && recon && loss_out && drecon && n > 0, "cy_recon_loss_add: bad arguments");
+  recon_loss_kernel<<<1, LT, 0, (hipStream_t)stream>>>(x, recon, coef_over_B, loss_out, drecon, n);
+  CY_LAUNCH_CHECK("cy_recon_loss_add");
+  return 0;
+}
+
+extern "C" int cy_dark_loss(const float* y_pred, const double* y_true, float* loss_out, float* avg_iou_out, float* dpred,
+                            int B, int g, int nb, int C, float l_coord, float l_noobj, float img_size, void* stream) {
+  CY_REQUIRE(y_pred && y_true && loss_out && avg_iou_out && dpred && B > 0 && g > 0, "cy_dark_loss: bad arguments");
+  CY_REQUIRE(nb >= 1 && nb <= MAXNB && C >= 0, "cy_dark_loss: n_boxes must be 1..%d", MAXNB);
+  dark_loss_kernel<<<1, LT, 0, (hipStream_t)stream>>>(y_pred, y_true, loss_out, avg_iou_out, dpred, B * g * g, nb, C,
+                                                      l_coord, l_noobj, img_size, img_size / (float)g, 1.f / (float)B);
+  CY_LAUNCH_CHECK("cy_dark_loss");
+  return 0;
+}
+
+extern "C" int cy_scale_by_device_scalar(const float* in, const float* scalar, float* out, long long n, void* stream) {
+  CY_REQUIRE(in && scalar && out && n > 0, "cy_scale_by_device_scalar: bad arguments");
+  long long blocks = cy_ceil_div(n, 256);
+  if (blocks > 2048) blocks = 2048;
+  scale_by_scalar_kernel<<<(unsigned)blocks, 256, 0, (hipStream_t)stream>>>(in, scalar, out, n);
+  CY_LAUNCH_CHECK("cy_scale_by_device_scalar");
+  return 0;
+}

@@ -1,0 +1,212 @@
+// Small data-movement / elementwise kernels around the hot path (gfx950): layout permutes,
+// MaxPool2d(2), nearest Upsample, the YOLO head activation, tanh, capsule gather.
+// Replaces models.py:8-19 (Flatten/UnFlatten views), 80-82 (primary-capsule view+cat), 99-105
+// (nn.Upsample), 122 (torch.gather of the true capsule), 135-195 (nn.MaxPool2d), 226-236 (head).
+#include "common.h"
+
+namespace {
+
+inline unsigned grid_for(long long n) {
+  long long b = cy_ceil_div(n, 256);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+#define CY_GRID_STRIDE(i, n) \
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
+
+// generic 4-D permute: out[b][i1][i2][i3] (contiguous) = in[b*sb + i1*s1 + i2*s2 + i3*s3]
+__global__ void permute4_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int d1, int d2, int d3,
+                                long long sb, long long s1, long long s2, long long s3, int scatter) {
+  CY_GRID_STRIDE(i, n) {
+    long long r = i;
+    const int i3 = (int)(r % d3); r /= d3;
+    const int i2 = (int)(r % d2); r /= d2;
+    const int i1 = (int)(r % d1); r /= d1;
+    const long long j = r * sb + i1 * s1 + i2 * s2 + i3 * s3;
+    if (scatter) out[j] = in[i]; else out[i] = in[j];
+  }
+}
+
+// NHWC 2x2 max pooling; idx keeps the winning position (0..3) for the backward
+__global__ void maxpool2_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                    long long n, int Ho, int Wo, int C) {
+  CY_GRID_STRIDE(i, n) {
+    long long r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); r /= Ho;
+    const long long base = ((r * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+    const long long rs = (long long)2 * Wo * C;
+    float best = x[base]; int bi = 0;
+    float v = x[base + C]; if (v > best) { best = v; bi = 1; }
+    v = x[base + rs]; if (v > best) { best = v; bi = 2; }
+    v = x[base + rs + C]; if (v > best) { best = v; bi = 3; }
+    y[i] = best; idx[i] = (unsigned char)bi;
+  }
+}
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                    float* __restrict__ dx, long long n, int Ho, int Wo, int C) {
+  CY_GRID_STRIDE(i, n) {
+    long long r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); r /= Ho;
+    const long long base = ((r * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+    const long long rs = (long long)2 * Wo * C;
+    const int bi = idx[i];
+    const float g = dy[i];
+    dx[base] = bi == 0 ? g : 0.f;
+    dx[base + C] = bi == 1 ? g : 0.f;
+    dx[base + rs] = bi == 2 ? g : 0.f;
+    dx[base + rs + C] = bi == 3 ? g : 0.f;
+  }
+}
+
+// nearest-neighbour upsample by an integer factor f, NHWC
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int Hi, int Wi, int C,
+                                    int f) {
+  CY_GRID_STRIDE(i, n) {
+    long long r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ox = (int)(r % (Wi * f)); r /= (Wi * f);
+    const int oy = (int)(r % (Hi * f)); r /= (Hi * f);
+    y[i] = x[((r * Hi + oy / f) * Wi + ox / f) * C + c];
+  }
+}
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long n, int Hi, int Wi, int C,
+                                    int f) {
+  CY_GRID_STRIDE(i, n) {            // i over the INPUT elements
+    long long r = i;
+    const int c = (int)(r % C); r /= C;
+    const int ix = (int)(r % Wi); r /= Wi;
+    const int iy = (int)(r % Hi); r /= Hi;
+    float s = 0.f;
+    for (int a = 0; a < f; ++a)
+      for (int b = 0; b < f; ++b) s += dy[((r * Hi * f + iy * f + a) * (long long)(Wi * f) + ix * f + b) * C + c];
+    dx[i] = s;
+  }
+}
+
+__global__ void tanh_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n) {
+  CY_GRID_STRIDE(i, n) y[i] = tanhf(x[i]);
+}
+__global__ void tanh_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx, long long n) {
+  CY_GRID_STRIDE(i, n) dx[i] = dy[i] * (1.f - y[i] * y[i]);
+}
+
+// YOLO head (models.py:226-236): sigmoid on the first `split` channels of each cell, softmax on the rest
+__global__ void yolo_head_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long cells, int split, int C) {
+  CY_GRID_STRIDE(cell, cells) {
+    const float* xi = x + cell * (split + C);
+    float* yi = y + cell * (split + C);
+    for (int k = 0; k < split; ++k) yi[k] = 1.f / (1.f + expf(-xi[k]));
+    if (C > 0) {
+      float m = -INFINITY, s = 0.f;
+      for (int k = 0; k < C; ++k) m = fmaxf(m, xi[split + k]);
+      for (int k = 0; k < C; ++k) s += expf(xi[split + k] - m);
+      for (int k = 0; k < C; ++k) yi[split + k] = expf(xi[split + k] - m) / s;
+    }
+  }
+}
+__global__ void yolo_head_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy, float* __restrict__ dx,
+                                     long long cells, int split, int C) {
+  CY_GRID_STRIDE(cell, cells) {
+    const float* yi = y + cell * (split + C);
+    const float* gi = dy + cell * (split + C);
+    float* di = dx + cell * (split + C);
+    for (int k = 0; k < split; ++k) di[k] = gi[k] * yi[k] * (1.f - yi[k]);
+    if (C > 0) {
+      float dot = 0.f;
+      for (int k = 0; k < C; ++k) dot += gi[split + k] * yi[split + k];
+      for (int k = 0; k < C; ++k) di[split + k] = yi[split + k] * (gi[split + k] - dot);
+    }
+  }
+}
+
+// out[b][:] = caps[b][y[b]][:]  /  scatter of its gradient (zero elsewhere)
+__global__ void pick_capsule_kernel(const float* __restrict__ caps, const long long* __restrict__ y, float* __restrict__ out,
+                                    int B, int C, int D, int backward) {
+  const int n = backward ? B * C * D : B * D;
+  CY_GRID_STRIDE(i, n) {
+    if (!backward) {
+      const int b = (int)(i / D), d = (int)(i % D);
+      out[i] = caps[((long long)b * C + y[b]) * D + d];
+    } else {       // caps = d(out) [B][D], out = d(caps) [B][C][D]
+      const int d = (int)(i % D), c = (int)((i / D) % C), b = (int)(i / ((long long)C * D));
+      out[i] = (y[b] == c) ? caps[(long long)b * D + d] : 0.f;
+    }
+  }
+}
+
+}  // namespace
+
+#define CY_S ((hipStream_t)stream)
+
+extern "C" int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,
+                           long long s2, long long s3, int scatter, void* stream) {
+  CY_REQUIRE(in && out && nb > 0 && d1 > 0 && d2 > 0 && d3 > 0, "cy_permute4: bad arguments");
+  const long long n = nb * d1 * d2 * d3;
+  permute4_kernel<<<grid_for(n), 256, 0, CY_S>>>(in, out, n, d1, d2, d3, sb, s1, s2, s3, scatter);
+  CY_LAUNCH_CHECK("cy_permute4");
+  return 0;
+}
+extern "C" int cy_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int B, int Ho, int Wo, int C, void* stream) {
+  CY_REQUIRE(x && y && idx && B > 0 && Ho > 0 && Wo > 0 && C > 0, "cy_maxpool2_fwd: bad arguments");
+  const long long n = (long long)B * Ho * Wo * C;
+  maxpool2_fwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(x, y, idx, n, Ho, Wo, C);
+  CY_LAUNCH_CHECK("cy_maxpool2_fwd");
+  return 0;
+}
+extern "C" int cy_maxpool2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int Ho, int Wo, int C, void* stream) {
+  CY_REQUIRE(dy && dx && idx && B > 0 && Ho > 0 && Wo > 0 && C > 0, "cy_maxpool2_bwd: bad arguments");
+  const long long n = (long long)B * Ho * Wo * C;
+  maxpool2_bwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(dy, idx, dx, n, Ho, Wo, C);
+  CY_LAUNCH_CHECK("cy_maxpool2_bwd");
+  return 0;
+}
+extern "C" int cy_upsample_fwd(const float* x, float* y, int B, int Hi, int Wi, int C, int f, void* stream) {
+  CY_REQUIRE(x && y && B > 0 && Hi > 0 && Wi > 0 && C > 0 && f >= 1, "cy_upsample_fwd: bad arguments");
+  const long long n = (long long)B * Hi * f * Wi * f * C;
+  upsample_fwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(x, y, n, Hi, Wi, C, f);
+  CY_LAUNCH_CHECK("cy_upsample_fwd");
+  return 0;
+}
+extern "C" int cy_upsample_bwd(const float* dy, float* dx, int B, int Hi, int Wi, int C, int f, void* stream) {
+  CY_REQUIRE(dy && dx && B > 0 && Hi > 0 && Wi > 0 && C > 0 && f >= 1, "cy_upsample_bwd: bad arguments");
+  const long long n = (long long)B * Hi * Wi * C;
+  upsample_bwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(dy, dx, n, Hi, Wi, C, f);
+  CY_LAUNCH_CHECK("cy_upsample_bwd");
+  return 0;
+}
+extern "C" int cy_tanh_fwd(const float* x, float* y, long long n, void* stream) {
+  CY_REQUIRE(x && y && n > 0, "cy_tanh_fwd: bad arguments");
+  tanh_fwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(x, y, n);
+  CY_LAUNCH_CHECK("cy_tanh_fwd");
+  return 0;
+}
+extern "C" int cy_tanh_bwd(const float* y, const float* dy, float* dx, long long n, void* stream) {
+  CY_REQUIRE(y && dy && dx && n > 0, "cy_tanh_bwd: bad arguments");
+  tanh_bwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(y, dy, dx, n);
+  CY_LAUNCH_CHECK("cy_tanh_bwd");
+  return 0;
+}
+extern "C" int cy_yolo_head_fwd(const float* x, float* y, long long cells, int split, int C, void* stream) {
+  CY_REQUIRE(x && y && cells > 0 && split >= 0 && C >= 0 && split + C > 0, "cy_yolo_head_fwd: bad arguments");
+  yolo_head_fwd_kernel<<<grid_for(cells), 256, 0, CY_S>>>(x, y, cells, split, C);
+  CY_LAUNCH_CHECK("cy_yolo_head_fwd");
+  return 0;
+}
+extern "C" int cy_yolo_head_bwd(const float* y, const float* dy, float* dx, long long cells, int split, int C, void* stream) {
+  CY_REQUIRE(y && dy && dx && cells > 0 && split >= 0 && C >= 0 && split + C > 0, "cy_yolo_head_bwd: bad arguments");
+  yolo_head_bwd_kernel<<<grid_for(cells), 256, 0, CY_S>>>(y, dy, dx, cells, split, C);
+  CY_LAUNCH_CHECK("cy_yolo_head_bwd");
+  return 0;
+}
+extern "C" int cy_pick_capsule(const float* caps, const long long* y, float* out, int B, int C, int D, int backward, void* stream) {
+  CY_REQUIRE(caps && y && out && B > 0 && C > 0 && D > 0, "cy_pick_capsule: bad arguments");
+  const long long n = backward ? (long long)B * C * D : (long long)B * D;
+  pick_capsule_kernel<<<grid_for(n), 256, 0, CY_S>>>(caps, y, out, B, C, D, backward);
+  CY_LAUNCH_CHECK("cy_pick_capsule");
+  return 0;
+}

@@ -1,0 +1,723 @@
+// Capsule dynamic routing, all iterations in one launch, forward and backward (gfx950).
+//
+// Replaces CapsuleLayer.forward's routing branch (models.py:70-79) and its autograd backward.
+//   u_hat_ij = u_i W_ij ;  b^t_ij = u_hat_ij . V_t[j],  V_t = sum_{tau<t} v^tau   (the reference
+//   accumulates logits b += u_hat.v, which is the same sum -- logits are never stored);
+//   c^t = softmax_j(b^t) ; s^t_j = sum_i c^t_ij u_hat_ij ; v^t = squash(s^t).
+// u_hat is recomputed every iteration from (u, W) instead of being stored (the reference keeps a
+// [R,N,C,1,Dout] tensor and makes ~20 passes over it).
+//
+// Two code paths:
+//  * C == 1 (DarkCapsuleNet head, models.py:368-370): coupling == 1 exactly, the layer is
+//    v = squash(sum_i u_i W_i): a pure HBM stream over u (R rows of 4096 floats).  One block of 4
+//    waves walks rows; wave w owns quarter w of the row, whose 16 elements per lane meet W values
+//    held in registers.  With the NHWC feature map the "cell gather" (models.py:393-398) makes each
+//    quarter one contiguous 4 KiB segment, so the gather costs nothing.
+//  * general C <= 64: lanes <-> output capsule j, one wave per row.  The softmax over j is a
+//    wavefront reduction, s_j / V_j / the running sums are lane-local registers, W_i is staged
+//    once per block through LDS and shared by the block's rows.
+// Backward (general): B1 (same row decomposition) walks t = T-1..1 producing ds^t and V_t per
+// row; B2 (one wave per input capsule i, lanes <-> j) turns them into du and dW with the dW_i
+// tile accumulated in registers across all rows.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ helpers
+__device__ __forceinline__ void squash_vec(const float* s, float* v, int D) {
+  float n2 = 0.f;
+  for (int o = 0; o < D; ++o) n2 += s[o] * s[o];
+  const float f = (n2 / (1.f + n2)) / sqrtf(n2);          // no epsilon: 0 -> NaN like the reference
+  for (int o = 0; o < D; ++o) v[o] = f * s[o];
+}
+// ds = J^T dv for v = s * n/(1+n^2), n = |s|
+__device__ __forceinline__ void squash_bwd_vec(const float* s, const float* dv, float* ds, int D) {
+  float n2 = 0.f, sd = 0.f;
+  for (int o = 0; o < D; ++o) { n2 += s[o] * s[o]; sd += s[o] * dv[o]; }
+  const float n = sqrtf(n2);
+  const float h = n / (1.f + n2);
+  const float hp = (1.f - n2) / ((1.f + n2) * (1.f + n2));
+  const float k = sd * hp / n;
+  for (int o = 0; o < D; ++o) ds[o] = h * dv[o] + k * s[o];
+}
+
+// offset (in floats) of the Din-vector of input capsule i of row `row`
+__device__ __forceinline__ long long u_offset(int row, int i, int N, int Din, int g, int B) {
+  if (g == 0) return ((long long)row * N + i) * Din;
+  const int k = row / B, b = row - k * B;
+  const int pos = i >> 5, chg = i & 31;
+  const long long pix = (long long)b * 16 * g * g + (long long)(pos >> 2) * 4 * g * g + 4 * k + (pos & 3);
+  return pix * 256 + chg * 8;
+}
+// v_out / dv row index: with the cell gather the result is laid out [B][g*g] (what
+// view(g,g,B,.).permute(2,0,1,3) of models.py:399 presents), otherwise row order
+__device__ __forceinline__ long long out_row(int row, int g, int B) {
+  if (g == 0) return row;
+  const int k = row / B, b = row - k * B;
+  return (long long)b * g * g + k;
+}
+// offset of quarter w (1024 floats) of row `row` when N*Din == 4096
+__device__ __forceinline__ long long quarter_offset(int row, int w, int g, int B) {
+  if (g == 0) return (long long)row * 4096 + w * 1024;
+  const int k = row / B, b = row - k * B;
+  return ((long long)b * 16 * g * g + (long long)w * 4 * g * g + 4 * k) * 256;
+}
+
+// ================================================================================================ C == 1
+constexpr int C1_ROWS = 4;                  // rows in flight per block iteration
+
+template <int DOUT>
+__global__ __launch_bounds__(256) void caps1_fwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
+                                                        float* __restrict__ v_out, float* __restrict__ s_out, int R,
+                                                        int g, int B) {
+  __shared__ float part[2][4][C1_ROWS][8];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  // W[e][o], e = w*1024 + j*256 + lane*4 + q
+  float wr[4][4][DOUT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) wr[j][q][o] = W[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o];
+
+  const int ngroups = (R + C1_ROWS - 1) / C1_ROWS;
+  int buf = 0;
+  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, buf ^= 1) {
+    float4 x[C1_ROWS][4];
+#pragma unroll
+    for (int rr = 0; rr < C1_ROWS; ++rr) {
+      const int row = grp * C1_ROWS + rr;
+      if (row < R) {
+        const float4* src = (const float4*)(u + quarter_offset(row, w, g, B)) + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[rr][j] = src[j * 64];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int rr = 0; rr < C1_ROWS; ++rr) {
+      float acc[DOUT];
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) acc[o] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o)
+          acc[o] += x[rr][j].x * wr[j][0][o] + x[rr][j].y * wr[j][1][o] + x[rr][j].z * wr[j][2][o] +
+                    x[rr][j].w * wr[j][3][o];
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) {
+        const float s = wave_sum(acc[o]);
+        if (lane == 0) part[buf][w][rr][o] = s;
+      }
+    }
+    __syncthreads();
+    if (t < C1_ROWS) {
+      const int row = grp * C1_ROWS + t;
+      if (row < R) {
+        float s[DOUT], v[DOUT];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) s[o] = part[buf][0][t][o] + part[buf][1][t][o] + part[buf][2][t][o] + part[buf][3][t][o];
+        squash_vec(s, v, DOUT);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) { s_out[(long long)row * DOUT + o] = s[o]; v_out[out_row(row, g, B) * DOUT + o] = v[o]; }
+      }
+    }
+    // the other LDS buffer is used next iteration; the barrier of that iteration orders its reuse
+  }
+}
+
+template <int DOUT>
+__global__ __launch_bounds__(256) void caps1_bwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
+                                                        const float* __restrict__ s_in, const float* __restrict__ dv,
+                                                        float* __restrict__ du, float* __restrict__ slabs, int R,
+                                                        int g, int B, int rows_per_block) {
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  float wr[4][4][DOUT], dw[4][4][DOUT];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) {
+        wr[j][q][o] = W[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o];
+        dw[j][q][o] = 0.f;
+      }
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(R, r0 + rows_per_block);
+  for (int row = r0; row < r1; row += 2) {
+    const bool two = row + 1 < r1;
+    const long long off0 = quarter_offset(row, w, g, B);
+    const long long off1 = two ? quarter_offset(row + 1, w, g, B) : off0;
+    float4 x0[4], x1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x0[j] = ((const float4*)(u + off0))[lane + j * 64];
+      x1[j] = ((const float4*)(u + off1))[lane + j * 64];
+    }
+    float ds0[DOUT], ds1[DOUT];
+    {
+      float s[DOUT], d[DOUT];
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) { s[o] = s_in[(long long)row * DOUT + o]; d[o] = dv[out_row(row, g, B) * DOUT + o]; }
+      squash_bwd_vec(s, d, ds0, DOUT);
+      const int rb = two ? row + 1 : row;
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) { s[o] = s_in[(long long)rb * DOUT + o]; d[o] = dv[out_row(rb, g, B) * DOUT + o]; }
+      squash_bwd_vec(s, d, ds1, DOUT);
+      if (!two) {
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) ds1[o] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float g0[4], g1[4];
+      const float xa[4] = {x0[j].x, x0[j].y, x0[j].z, x0[j].w};
+      const float xb[4] = {x1[j].x, x1[j].y, x1[j].z, x1[j].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+          a0 += wr[j][q][o] * ds0[o];
+          a1 += wr[j][q][o] * ds1[o];
+          dw[j][q][o] += xa[q] * ds0[o] + xb[q] * ds1[o];
+        }
+        g0[q] = a0; g1[q] = a1;
+      }
+      ((float4*)(du + off0))[lane + j * 64] = make_float4(g0[0], g0[1], g0[2], g0[3]);
+      if (two) ((float4*)(du + off1))[lane + j * 64] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+    }
+  }
+  float* slab = slabs + (long long)blockIdx.x * 4096 * DOUT;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) slab[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o] = dw[j][q][o];
+}
+
+__global__ void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslabs, long long n) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += slabs[(long long)k * n + i];
+  out[i] = s;
+}
+
+// ================================================================================================ general C
+template <int DIN, int DOUT>
+struct WTile {
+  static constexpr int DD = DIN * DOUT;
+  static constexpr bool V4 = (DOUT % 4 == 0);
+  static constexpr int WS = V4 ? DD + 4 : (DD | 1);        // LDS row stride (floats) per output capsule j
+  static constexpr int MAXC = 64;
+  static constexpr int NREG = V4 ? (MAXC * DD / 4 + 255) / 256 : (MAXC * DD + 255) / 256;
+};
+
+// cooperative global -> register -> LDS staging of one W_i tile ([C][DD] contiguous in global)
+template <int DIN, int DOUT>
+struct WStage {
+  using T = WTile<DIN, DOUT>;
+  float4 r4[T::V4 ? T::NREG : 1];
+  float r1[T::V4 ? 1 : T::NREG];
+  __device__ __forceinline__ void load(const float* __restrict__ Wi, int C, int t) {
+    if (T::V4) {
+      const int n4 = C * T::DD / 4;
+#pragma unroll
+      for (int k = 0; k < T::NREG; ++k) {
+        const int idx = t + 256 * k;
+        r4[k] = (idx < n4) ? ((const float4*)Wi)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    } else {
+      const int n = C * T::DD;
+#pragma unroll
+      for (int k = 0; k < T::NREG; ++k) { const int idx = t + 256 * k; r1[k] = (idx < n) ? Wi[idx] : 0.f; }
+    }
+  }
+  __device__ __forceinline__ void store(float* __restrict__ Wl, int C, int t) const {
+    if (T::V4) {
+      const int n4 = C * T::DD / 4;
+#pragma unroll
+      for (int k = 0; k < T::NREG; ++k) {
+        const int idx = t + 256 * k;
+        if (idx < n4) { const int j = (idx * 4) / T::DD, rem = (idx * 4) % T::DD; *(float4*)(Wl + j * T::WS + rem) = r4[k]; }
+      }
+    } else {
+      const int n = C * T::DD;
+#pragma unroll
+      for (int k = 0; k < T::NREG; ++k) {
+        const int idx = t + 256 * k;
+        if (idx < n) { const int j = idx / T::DD, rem = idx % T::DD; Wl[j * T::WS + rem] = r1[k]; }
+      }
+    }
+  }
+};
+
+// u_hat[rr][o] = sum_d u[rr][d] * W_l[d*DOUT + o] for the wave's rows (W row read once for all rows)
+template <int DIN, int DOUT, int RW>
+__device__ __forceinline__ void predict(const float* __restrict__ Wl, const float (&uv)[RW][DIN], float (&uh)[RW][DOUT]) {
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) uh[rr][o] = 0.f;
+#pragma unroll
+  for (int d = 0; d < DIN; ++d) {
+    float wrow[DOUT];
+    if (DOUT % 4 == 0) {
+#pragma unroll
+      for (int o4 = 0; o4 < DOUT / 4; ++o4) {
+        const float4 v = *(const float4*)(Wl + d * DOUT + o4 * 4);
+        wrow[o4 * 4] = v.x; wrow[o4 * 4 + 1] = v.y; wrow[o4 * 4 + 2] = v.z; wrow[o4 * 4 + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) wrow[o] = Wl[d * DOUT + o];
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) uh[rr][o] += uv[rr][d] * wrow[o];
+  }
+}
+
+template <int DIN, int DOUT, int RW>
+__global__ __launch_bounds__(256) void routing_fwd_kernel(cy_routing_fwd_t a) {
+  using T = WTile<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][C][WS]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int C = a.C, N = a.N, R = a.R;
+  const int tile = C * T::WS;
+  const bool jv = lane < C;
+  const int jl = jv ? lane : 0;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  const long long CD = (long long)C * DOUT;
+  const float invC = 1.0f / (float)C;
+
+  float V[RW][DOUT];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) V[rr][o] = 0.f;
+
+  WStage<DIN, DOUT> stage;
+  for (int it = 0; it < a.n_iter; ++it) {
+    float sacc[RW][DOUT];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr)
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) sacc[rr][o] = 0.f;
+
+    __syncthreads();                       // previous iteration's readers are done with both buffers
+    stage.load(a.W, C, t);
+    stage.store(smem, C, t);
+    __syncthreads();
+    for (int i = 0; i < N; ++i) {
+      const int cur = i & 1;
+      if (i + 1 < N) stage.load(a.W + (long long)(i + 1) * C * T::DD, C, t);
+      const float* Wl = smem + cur * tile + jl * T::WS;
+      float uv[RW][DIN], uh[RW][DOUT];
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        const int row = row0 + rr;
+        if (row < R) {
+          const float* up = a.u + u_offset(row, i, N, DIN, a.gather_g, a.gather_B);
+#pragma unroll
+          for (int d = 0; d < DIN; ++d) uv[rr][d] = up[d];
+        } else {
+#pragma unroll
+          for (int d = 0; d < DIN; ++d) uv[rr][d] = 0.f;
+        }
+      }
+      predict<DIN, DOUT, RW>(Wl, uv, uh);
+#pragma unroll
+      for (int rr = 0; rr < RW; ++rr) {
+        float c = invC;
+        if (it > 0) {
+          float b = 0.f;
+#pragma unroll
+          for (int o = 0; o < DOUT; ++o) b += uh[rr][o] * V[rr][o];
+          b = jv ? b : -INFINITY;
+          const float m = wave_max(b);
+          const float e = jv ? expf(b - m) : 0.f;
+          c = e / wave_sum(e);
+        }
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) sacc[rr][o] += c * uh[rr][o];
+      }
+      if (i + 1 < N) stage.store(smem + (cur ^ 1) * tile, C, t);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const int row = row0 + rr;
+      if (row < R && jv) {
+        float v[DOUT];
+        squash_vec(sacc[rr], v, DOUT);
+        float* sh = a.s_hist + ((long long)it * R + row) * CD + (long long)lane * DOUT;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) { sh[o] = sacc[rr][o]; V[rr][o] += v[o]; }
+        if (it == a.n_iter - 1) {
+          float* vo = a.v_out + out_row(row, a.gather_g, a.gather_B) * CD + (long long)lane * DOUT;
+#pragma unroll
+          for (int o = 0; o < DOUT; ++o) vo[o] = v[o];
+        }
+      }
+    }
+  }
+}
+
+// ---- backward B1: per row, t = T-1..0 -> ds_all[t], V_all[t]   (ws = [2][T][R][C][DOUT])
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(256) void routing_bwd_rows_kernel(cy_routing_bwd_t a) {
+  using T = WTile<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int C = a.C, N = a.N, R = a.R, NT = a.n_iter;
+  const int tile = C * T::WS;
+  const bool jv = lane < C;
+  const int jl = jv ? lane : 0;
+  const int row = blockIdx.x * 4 + wave;
+  const bool rv = row < R;
+  const long long CD = (long long)C * DOUT;
+  const long long plane = (long long)R * CD;
+  float* ds_all = a.ws;
+  float* V_all = a.ws + (long long)NT * plane;
+  const long long my = (long long)(rv ? row : 0) * CD + (long long)jl * DOUT;
+
+  float SA[DOUT];
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) SA[o] = 0.f;
+  WStage<DIN, DOUT> stage;
+
+  for (int it = NT - 1; it >= 0; --it) {
+    float Vt[DOUT], ds[DOUT];
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) { Vt[o] = 0.f; ds[o] = 0.f; }
+    if (rv && jv) {
+      for (int tau = 0; tau < it; ++tau) {
+        float s[DOUT], v[DOUT];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) s[o] = a.s_hist[(long long)tau * plane + my + o];
+        squash_vec(s, v, DOUT);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) Vt[o] += v[o];
+      }
+      float s[DOUT], dvv[DOUT];
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) {
+        s[o] = a.s_hist[(long long)it * plane + my + o];
+        dvv[o] = SA[o] + (it == NT - 1 ? a.dv[out_row(row, a.gather_g, a.gather_B) * CD + (long long)jl * DOUT + o] : 0.f);
+      }
+      squash_bwd_vec(s, dvv, ds, DOUT);
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) { ds_all[(long long)it * plane + my + o] = ds[o]; V_all[(long long)it * plane + my + o] = Vt[o]; }
+    }
+    if (it == 0) break;
+
+    float A[DOUT];
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) A[o] = 0.f;
+    __syncthreads();
+    stage.load(a.W, C, t);
+    stage.store(smem, C, t);
+    __syncthreads();
+    for (int i = 0; i < N; ++i) {
+      const int cur = i & 1;
+      if (i + 1 < N) stage.load(a.W + (long long)(i + 1) * C * T::DD, C, t);
+      const float* Wl = smem + cur * tile + jl * T::WS;
+      float uv[1][DIN], uh[1][DOUT];
+      if (rv) {
+        const float* up = a.u + u_offset(row, i, N, DIN, a.gather_g, a.gather_B);
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) uv[0][d] = up[d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) uv[0][d] = 0.f;
+      }
+      predict<DIN, DOUT, 1>(Wl, uv, uh);
+      float b = 0.f, dc = 0.f;
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) { b += uh[0][o] * Vt[o]; dc += uh[0][o] * ds[o]; }
+      b = jv ? b : -INFINITY;
+      const float m = wave_max(b);
+      const float e = jv ? expf(b - m) : 0.f;
+      const float c = e / wave_sum(e);
+      const float dot = wave_sum(c * dc);
+      const float db = c * (dc - dot);
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) A[o] += db * uh[0][o];
+      if (i + 1 < N) stage.store(smem + (cur ^ 1) * tile, C, t);
+      __syncthreads();
+    }
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) SA[o] += A[o];
+  }
+}
+
+// ---- backward B2: wave <-> input capsule i, lanes <-> j; dW_i accumulated in registers over the rows
+template <int DIN, int DOUT>
+__global__ __launch_bounds__(256, 1) void routing_bwd_caps_kernel(cy_routing_bwd_t a, int rows_per_chunk) {
+  using T = WTile<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][C][WS]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int C = a.C, N = a.N, R = a.R, NT = a.n_iter;
+  const int i = blockIdx.x * 4 + wave;
+  const bool iv = i < N;
+  const bool jv = lane < C;
+  const int jl = jv ? lane : 0;
+  const long long CD = (long long)C * DOUT;
+  const long long plane = (long long)R * CD;
+  const float* ds_all = a.ws;
+  const float* V_all = a.ws + (long long)NT * plane;
+  const float invC = 1.0f / (float)C;
+  float* Wme = smem + wave * C * T::WS;
+
+  // this wave's W_i -> its private LDS region (wave-local, but a block barrier keeps it simple)
+  if (iv) {
+    const float* Wi = a.W + (long long)i * C * T::DD;
+    for (int idx = lane; idx < C * T::DD; idx += 64) Wme[(idx / T::DD) * T::WS + idx % T::DD] = Wi[idx];
+  }
+  __syncthreads();
+  const float* Wl = Wme + jl * T::WS;
+
+  float dw[DIN][DOUT];
+#pragma unroll
+  for (int d = 0; d < DIN; ++d)
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) dw[d][o] = 0.f;
+
+  const int r0 = blockIdx.y * rows_per_chunk;
+  const int r1 = min(R, r0 + rows_per_chunk);
+  if (iv) {
+    for (int row = r0; row < r1; ++row) {
+      const long long uoff = u_offset(row, i, N, DIN, a.gather_g, a.gather_B);
+      float uv[1][DIN], uh[1][DOUT], duh[DOUT];
+#pragma unroll
+      for (int d = 0; d < DIN; ++d) uv[0][d] = a.u[uoff + d];
+      predict<DIN, DOUT, 1>(Wl, uv, uh);
+      const long long my = (long long)row * CD + (long long)jl * DOUT;
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) duh[o] = jv ? invC * ds_all[my + o] : 0.f;
+      for (int it = 1; it < NT; ++it) {
+        float Vt[DOUT], ds[DOUT];
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) { Vt[o] = V_all[(long long)it * plane + my + o]; ds[o] = ds_all[(long long)it * plane + my + o]; }
+        float b = 0.f, dc = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) { b += uh[0][o] * Vt[o]; dc += uh[0][o] * ds[o]; }
+        b = jv ? b : -INFINITY;
+        const float m = wave_max(b);
+        const float e = jv ? expf(b - m) : 0.f;
+        const float c = e / wave_sum(e);
+        const float dot = wave_sum(c * dc);
+        const float db = c * (dc - dot);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) duh[o] += jv ? (c * ds[o] + db * Vt[o]) : 0.f;
+      }
+      // du_i[d] = sum_j sum_o W[j][d][o] * duh_j[o]
+      float mine = 0.f;
+#pragma unroll
+      for (int d = 0; d < DIN; ++d) {
+        float p = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+          const float wv = Wl[d * DOUT + o];
+          p += wv * duh[o];
+          dw[d][o] += uv[0][d] * duh[o];
+        }
+        p = wave_sum(jv ? p : 0.f);
+        if (lane == d) mine = p;
+      }
+      if (lane < DIN) a.du[uoff + lane] = mine;
+    }
+  }
+  // dW_i: registers -> wave's LDS region -> coalesced atomics (row chunks add into the same tile)
+  __syncthreads();
+  if (iv) {
+    if (jv) {
+#pragma unroll
+      for (int d = 0; d < DIN; ++d)
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) Wme[lane * T::WS + d * DOUT + o] = dw[d][o];
+    }
+  }
+  __syncthreads();
+  if (iv) {
+    float* dWi = a.dW + (long long)i * C * T::DD;
+    for (int idx = lane; idx < C * T::DD; idx += 64) atomicAdd(dWi + idx, Wme[(idx / T::DD) * T::WS + idx % T::DD]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ small vector ops
+__global__ void squash_fwd_kernel(const float* __restrict__ s, float* __restrict__ v, long long rows, int D) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float n2 = 0.f;
+  for (int o = 0; o < D; ++o) { const float x = s[r * D + o]; n2 += x * x; }
+  const float f = (n2 / (1.f + n2)) / sqrtf(n2);
+  for (int o = 0; o < D; ++o) v[r * D + o] = f * s[r * D + o];
+}
+__global__ void squash_bwd_kernel(const float* __restrict__ s, const float* __restrict__ dv, float* __restrict__ ds,
+                                  long long rows, int D) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float n2 = 0.f, sd = 0.f;
+  for (int o = 0; o < D; ++o) { const float x = s[r * D + o]; n2 += x * x; sd += x * dv[r * D + o]; }
+  const float n = sqrtf(n2), h = n / (1.f + n2), hp = (1.f - n2) / ((1.f + n2) * (1.f + n2));
+  const float k = sd * hp / n;
+  for (int o = 0; o < D; ++o) ds[r * D + o] = h * dv[r * D + o] + k * s[r * D + o];
+}
+__global__ void length_fwd_kernel(const float* __restrict__ v, float* __restrict__ len, long long rows, int D) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float n2 = 0.f;
+  for (int o = 0; o < D; ++o) { const float x = v[r * D + o]; n2 += x * x; }
+  len[r] = sqrtf(n2);
+}
+__global__ void length_bwd_kernel(const float* __restrict__ v, const float* __restrict__ len,
+                                  const float* __restrict__ dlen, float* __restrict__ dv, long long rows, int D) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float k = dlen[r] / len[r];          // 0/0 -> NaN at a zero capsule, like (x**2).sum()**0.5
+  for (int o = 0; o < D; ++o) dv[r * D + o] = k * v[r * D + o];
+}
+
+bool fast_c1(int N, int C, int Din, int Dout) { return C == 1 && N * Din == 4096 && Dout == 5; }
+
+template <int DIN, int DOUT>
+int launch_fwd(const cy_routing_fwd_t* a, hipStream_t s) {
+  using T = WTile<DIN, DOUT>;
+  constexpr int RW = (DOUT <= 16) ? 2 : 1;
+  const size_t lds = (size_t)2 * a->C * T::WS * 4;
+  const int blocks = (a->R + 4 * RW - 1) / (4 * RW);
+  int rc = cy_allow_lds(routing_fwd_kernel<DIN, DOUT, RW>, lds);
+  if (rc) return rc;
+  routing_fwd_kernel<DIN, DOUT, RW><<<blocks, 256, lds, s>>>(*a);
+  return 0;
+}
+template <int DIN, int DOUT>
+int launch_bwd(const cy_routing_bwd_t* a, hipStream_t s) {
+  using T = WTile<DIN, DOUT>;
+  const size_t lds1 = (size_t)2 * a->C * T::WS * 4;
+  int rc = cy_allow_lds(routing_bwd_rows_kernel<DIN, DOUT>, lds1);
+  if (rc) return rc;
+  routing_bwd_rows_kernel<DIN, DOUT><<<(a->R + 3) / 4, 256, lds1, s>>>(*a);
+  const int igroups = (a->N + 3) / 4;
+  int chunks = (768 + igroups - 1) / igroups;
+  if (chunks > (a->R + 15) / 16) chunks = (a->R + 15) / 16;
+  if (chunks < 1) chunks = 1;
+  const int rpc = (a->R + chunks - 1) / chunks;
+  chunks = (a->R + rpc - 1) / rpc;
+  const size_t lds2 = (size_t)4 * a->C * T::WS * 4;
+  rc = cy_allow_lds(routing_bwd_caps_kernel<DIN, DOUT>, lds2);
+  if (rc) return rc;
+  routing_bwd_caps_kernel<DIN, DOUT><<<dim3(igroups, chunks), 256, lds2, s>>>(*a, rpc);
+  return 0;
+}
+
+int check_shape(const char* fn, int R, int N, int C, int Din, int Dout, int n_iter, int g, int B) {
+  if (R <= 0 || N <= 0 || C <= 0 || n_iter <= 0) return cy_set_error(CY_EINVAL, "%s: non-positive dimension", fn);
+  if (g != 0 && (N != 512 || Din != 8 || B <= 0 || R != g * g * B))
+    return cy_set_error(CY_EINVAL, "%s: cell gather needs N=512, Din=8, R=g*g*B (got N=%d Din=%d R=%d g=%d B=%d)", fn, N,
+                        Din, R, g, B);
+  if (fast_c1(N, C, Din, Dout)) return 0;
+  if (Din != 8 || !(Dout == 5 || Dout == 16 || Dout == 21) || C > 64)
+    return cy_set_error(CY_EINVAL, "%s: unsupported capsule shape C=%d Din=%d Dout=%d (built: Din=8, Dout in {5,16,21}, C<=64)",
+                        fn, C, Din, Dout);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream) {
+  CY_REQUIRE(a && a->u && a->W && a->v_out && a->s_hist, "cy_routing_fwd: null pointer");
+  int rc = check_shape("cy_routing_fwd", a->R, a->N, a->C, a->Din, a->Dout, a->n_iter, a->gather_g, a->gather_B);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (fast_c1(a->N, a->C, a->Din, a->Dout)) {
+    const int groups = (a->R + C1_ROWS - 1) / C1_ROWS;
+    const int blocks = groups < 1024 ? groups : 1024;
+    float* s_last = a->s_hist + (long long)(a->n_iter - 1) * a->R * 5;
+    caps1_fwd_kernel<5><<<blocks, 256, 0, s>>>(a->u, a->W, a->v_out, s_last, a->R, a->gather_g, a->gather_B);
+  } else if (a->Dout == 5) rc = launch_fwd<8, 5>(a, s);
+  else if (a->Dout == 16) rc = launch_fwd<8, 16>(a, s);
+  else rc = launch_fwd<8, 21>(a, s);
+  if (rc) return rc;
+  CY_LAUNCH_CHECK("cy_routing_fwd");
+  return 0;
+}
+
+extern "C" long long cy_routing_bwd_ws_floats(const cy_routing_bwd_t* a) {
+  if (!a) return 0;
+  if (fast_c1(a->N, a->C, a->Din, a->Dout)) return 256ll * 4096 * 5;
+  return 2ll * a->n_iter * a->R * a->C * a->Dout;
+}
+
+extern "C" int cy_routing_bwd(const cy_routing_bwd_t* a, void* stream) {
+  CY_REQUIRE(a && a->u && a->W && a->s_hist && a->dv && a->du && a->dW && a->ws, "cy_routing_bwd: null pointer");
+  int rc = check_shape("cy_routing_bwd", a->R, a->N, a->C, a->Din, a->Dout, a->n_iter, a->gather_g, a->gather_B);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (fast_c1(a->N, a->C, a->Din, a->Dout)) {
+    int blocks = 256;
+    if (blocks > (a->R + 1) / 2) blocks = (a->R + 1) / 2;
+    int rpb = (a->R + blocks - 1) / blocks;
+    rpb = (rpb + 1) / 2 * 2;
+    blocks = (a->R + rpb - 1) / rpb;
+    const float* s_last = a->s_hist + (long long)(a->n_iter - 1) * a->R * 5;
+    caps1_bwd_kernel<5><<<blocks, 256, 0, s>>>(a->u, a->W, s_last, a->dv, a->du, a->ws, a->R, a->gather_g, a->gather_B, rpb);
+    CY_LAUNCH_CHECK("cy_routing_bwd(c1)");
+    const long long n = 4096ll * 5;
+    slab_sum_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(a->ws, a->dW, blocks, n);
+    CY_LAUNCH_CHECK("cy_routing_bwd(c1 reduce)");
+    return 0;
+  }
+  hipError_t e = hipMemsetAsync(a->dW, 0, (size_t)a->N * a->C * a->Din * a->Dout * 4, s);
+  if (e != hipSuccess) return cy_set_error((int)e, "cy_routing_bwd: memset: %s", hipGetErrorString(e));
+  if (a->Dout == 5) rc = launch_bwd<8, 5>(a, s);
+  else if (a->Dout == 16) rc = launch_bwd<8, 16>(a, s);
+  else rc = launch_bwd<8, 21>(a, s);
+  if (rc) return rc;
+  CY_LAUNCH_CHECK("cy_routing_bwd");
+  return 0;
+}
+
+#define CY_ROWS_LAUNCH(kernel, ...)                                                              \
+  kernel<<<(unsigned)cy_ceil_div(rows, 256), 256, 0, (hipStream_t)stream>>>(__VA_ARGS__, rows, D)
+
+extern "C" int cy_squash_fwd(const float* s, float* v, long long rows, int D, void* stream) {
+  CY_REQUIRE(s && v && rows > 0 && D > 0, "cy_squash_fwd: bad arguments");
+  CY_ROWS_LAUNCH(squash_fwd_kernel, s, v);
+  CY_LAUNCH_CHECK("cy_squash_fwd");
+  return 0;
+}
+extern "C" int cy_squash_bwd(const float* s, const float* dv, float* ds, long long rows, int D, void* stream) {
+  CY_REQUIRE(s && dv && ds && rows > 0 && D > 0, "cy_squash_bwd: bad arguments");
+  CY_ROWS_LAUNCH(squash_bwd_kernel, s, dv, ds);
+  CY_LAUNCH_CHECK("cy_squash_bwd");
+  return 0;
+}
+extern "C" int cy_length_fwd(const float* v, float* len, long long rows, int D, void* stream) {
+  CY_REQUIRE(v && len && rows > 0 && D > 0, "cy_length_fwd: bad arguments");
+  CY_ROWS_LAUNCH(length_fwd_kernel, v, len);
+  CY_LAUNCH_CHECK("cy_length_fwd");
+  return 0;
+}
+extern "C" int cy_length_bwd(const float* v, const float* len, const float* dlen, float* dv, long long rows, int D,
+                             void* stream) {
+  CY_REQUIRE(v && len && dlen && dv && rows > 0 && D > 0, "cy_length_bwd: bad arguments");
+  CY_ROWS_LAUNCH(length_bwd_kernel, v, len, dlen, dv);
+  CY_LAUNCH_CHECK("cy_length_bwd");
+  return 0;
+}

@@ -1,0 +1,37 @@
+"""Losses with the reference's names and call signatures (loss_fns.py), each ONE fused HIP kernel
+producing the value and the input gradient (csrc/loss.hip)."""
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+
+def cnn_loss(scores, y, params):
+    """loss_fns.py:6-8 (plain-torch baseline model, not a kernel target)."""
+    return (-F.log_softmax(scores, dim=1).gather(1, y.unsqueeze(1))).sum() / y.size(0)
+
+
+def capsule_loss(scores, y, params, x=None, recon=None):
+    """loss_fns.py:11-23."""
+    if params.recon:
+        return ops.capsule_loss_fn(scores, y, x, recon, params.recon_coef)
+    return ops.capsule_loss_fn(scores, y)
+
+
+def dark_loss(y_pred, y_true, params):
+    """loss_fns.py:60-142; writes params.avg_iou like the reference (loss_fns.py:141)."""
+    loss, avg_iou = ops.dark_loss_fn(y_pred, y_true, params.n_boxes, params.n_classes, params.l_coord,
+                                     params.l_noobj, params.darknet_input)
+    params.avg_iou = avg_iou
+    return loss
+
+
+def darkcapsule_loss(caps, y, params, x=None, recon=None):
+    """loss_fns.py:187-204.  With params.recon set the reference crashes for this model
+    (F.mse_loss(None, None)); here the same call raises a clear error instead."""
+    if params.recon:
+        if x is None or recon is None:
+            raise TypeError('darkcapsule_loss: params.recon is set but no (x, recon) were passed; '
+                            'run with --recon (store_false) as the reference requires for this model')
+        return ops.darkcapsule_loss_fn(caps, y) + ((x - recon) ** 2).sum()
+    return ops.darkcapsule_loss_fn(caps, y)

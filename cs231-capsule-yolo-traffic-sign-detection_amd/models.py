@@ -1,0 +1,277 @@
+"""Model zoo on the HIP kernels: same classes, constructor signature (``ModelCls(params)``), forward
+contract and ``state_dict`` keys as the reference's models.py, so reference checkpoints load and the
+``main.py`` registry is unchanged.  Internally activations are NHWC and every layer is a call into
+libcapsyolo_hip.so (see ops.py); inputs arrive NCHW fp32 as in main.py:57.
+
+New optional ``params`` keys: ``n_iter`` (routing iterations, default 3).
+"""
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------------------------ building blocks
+class HipConv2d(nn.Module):
+    """Parameter holder with nn.Conv2d's names/shapes/init (models.py: every nn.Conv2d)."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, bias=True):
+        super().__init__()
+        ref = nn.Conv2d(cin, cout, k, stride, padding=padding, bias=bias)     # torch's default init
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+        self.k, self.stride, self.padding = k, stride, padding
+
+    def forward(self, x, nchw_in=False, slope=None):
+        cfg = ops.ConvBlockCfg(self.k, self.stride, self.padding, nchw_in, None, slope)
+        return ops.conv_block(x, self.weight, self.bias, None, None, cfg)
+
+
+class HipBatchNorm2d(nn.Module):
+    """Parameter/buffer holder with nn.BatchNorm2d's names (weight, bias, running_*, num_batches_tracked)."""
+
+    def __init__(self, n, momentum=0.1, eps=1e-5):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+        self.register_buffer('running_mean', torch.zeros(n))
+        self.register_buffer('running_var', torch.ones(n))
+        self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
+        self.momentum, self.eps = momentum, eps
+
+
+class HipLeakyReLU(nn.Module):
+    def __init__(self, slope):
+        super().__init__()
+        self.slope = slope
+
+
+class HipMaxPool2(nn.Module):
+    def forward(self, x):
+        return ops.maxpool2(x)
+
+
+class FusedBackbone(nn.Sequential):
+    """nn.Sequential of conv_k / bn_k / relu_k / maxpool_k / drop_k children (reference names);
+    forward walks the children and fuses each conv -> bn -> relu triple into one conv block."""
+
+    def forward(self, x, nchw_in=True):
+        mods = list(self.children())
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, HipConv2d):
+                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], HipBatchNorm2d) else None
+                j = i + (2 if bn is not None else 1)
+                act = mods[j] if j < len(mods) and isinstance(mods[j], HipLeakyReLU) else None
+                cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, act.slope if act is not None else None)
+                x = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
+                                   bn.bias if bn is not None else None, cfg)
+                nchw_in = False
+                i = j + (1 if act is not None else 0)
+            elif isinstance(m, nn.Dropout):
+                if m.p > 0 and self.training:
+                    x = F.dropout(x, m.p, True)      # torch RNG kept (RNG parity)
+                i += 1
+            else:
+                x = m(x)
+                i += 1
+        return x
+
+
+def _cbl(seq, idx, cin, cout, k, stride=1, pad=0, bias=True, momentum=0.1):
+    seq['conv_%d' % idx] = HipConv2d(cin, cout, k, stride, pad, bias)
+    seq['bn_%d' % idx] = HipBatchNorm2d(cout, momentum)
+    seq['relu_%d' % idx] = HipLeakyReLU(0.1)
+
+
+class CapsuleLayer(nn.Module):
+    """models.py:46-83.  n_nodes != -1: routing layer holding ``route_weights``; n_nodes == -1:
+    primary capsules (n_caps parallel convs, run as ONE fused conv with n_caps*out_C channels)."""
+
+    def __init__(self, params, n_caps, n_nodes, in_C, out_C, kernel=None, stride=None, n_iter=3):
+        super().__init__()
+        self.params, self.n_iter, self.n_nodes, self.n_caps = params, n_iter, n_nodes, n_caps
+        if n_nodes != -1:
+            self.route_weights = nn.Parameter(0.1 * torch.randn(1, n_nodes, n_caps, in_C, out_C))
+        else:
+            self.capsules = nn.ModuleList([HipConv2d(in_C, out_C, kernel, stride) for _ in range(n_caps)])
+            self.kernel, self.stride = kernel, stride
+
+    def forward(self, x, gather_g=0, gather_B=0):
+        if self.n_nodes != -1:
+            return ops.routing(x, self.route_weights, self.n_iter, gather_g, gather_B)
+        # fused weight: output channel o*n_caps + cap  <-  capsules[cap].weight[o]
+        w = torch.stack([c.weight for c in self.capsules], dim=1)
+        w = w.reshape(-1, w.shape[2], self.kernel, self.kernel)
+        b = torch.stack([c.bias for c in self.capsules], dim=1).reshape(-1)
+        cfg = ops.ConvBlockCfg(self.kernel, self.stride, 0, False, None, None)
+        z = ops.conv_block(x, w, b, None, None, cfg)                      # [B,h,w,out_C*n_caps]
+        return ops.squash(ops.primary_caps_rows(z, self.n_caps))         # [B, out_C*h*w, n_caps]
+
+
+class Decoder(nn.Sequential):
+    """models.py:96-111: Linear(16,256) ReLU UnFlatten Upsample conv ReLU Upsample conv ReLU Upsample conv ReLU conv Tanh.
+    Children sit at the reference's indices (0,4,7,10,12 hold parameters)."""
+
+    def __init__(self):
+        lin = nn.Linear(16, 16 * 4 * 4)
+        super().__init__(lin, nn.Identity(), nn.Identity(), nn.Identity(),
+                         HipConv2d(16, 4, 3, 1, 1), nn.Identity(), nn.Identity(),
+                         HipConv2d(4, 8, 3, 1, 1), nn.Identity(), nn.Identity(),
+                         HipConv2d(8, 16, 3, 1, 1), nn.Identity(),
+                         HipConv2d(16, 3, 3, 1, 1), nn.Identity())
+
+    def forward(self, t):
+        B = t.shape[0]
+        lin = self[0]
+        cfg = ops.ConvBlockCfg(1, 1, 0, False, None, 0.0)
+        h = ops.conv_block(t.view(B, 1, 1, 16), lin.weight.view(256, 16, 1, 1), lin.bias, None, None, cfg)  # ReLU fused
+        h = ops.nchw_to_nhwc(h.view(B, 16, 4, 4))                      # UnFlatten(16,4,4) is an NCHW view
+        h = self[4](ops.upsample_nearest(h, 2), slope=0.0)
+        h = self[7](ops.upsample_nearest(h, 2), slope=0.0)
+        h = self[10](ops.upsample_nearest(h, 2), slope=0.0)
+        h = ops.tanh(self[12](h))
+        return ops.nhwc_to_nchw(h)                                     # [B,3,32,32] like the reference
+
+
+class CapsuleNet(nn.Module):
+    """models.py:86-124."""
+
+    def __init__(self, params):
+        super().__init__()
+        n_iter = getattr(params, 'n_iter', 3)
+        self.conv1 = HipConv2d(3, 256, 9)
+        self.primary_capsules = CapsuleLayer(params, n_caps=8, n_nodes=-1, in_C=256, out_C=16, kernel=8, stride=2)
+        self.traffic_sign_capsules = CapsuleLayer(params, n_caps=params.n_classes, n_nodes=16 * 9 * 9, in_C=8,
+                                                  out_C=16, n_iter=n_iter)
+        self.decoder = Decoder()
+
+    def forward(self, x, y=None, recon=False):
+        h = self.conv1(x, nchw_in=True, slope=0.0)                     # relu(conv1(x)), NHWC
+        u = self.primary_capsules(h)                                   # [B,1296,8]
+        caps = self.traffic_sign_capsules(u)                           # [B,C,16]
+        scores = ops.length(caps)
+        if not recon:
+            return scores
+        return scores, self.decoder(ops.pick_capsule(caps, y))
+
+
+_DARKNET_PLAN = [
+    (32, 3, 'M'), (64, 3, 'M'), (128, 3, 'D'), (64, 1, 'D'), (128, 3, 'M'),
+    (256, 3, 'D'), (128, 1, 'D'), (256, 3, 'M'),
+    (512, 3, 'D'), (256, 1, 'D'), (512, 3, 'D'), (256, 1, 'D'), (512, 3, 'M'),
+    (1024, 3, 'D'), (512, 1, 'D'), (1024, 3, 'D'), (512, 1, 'D'), (1024, 3, 'D'),
+]
+
+
+class DarkNet(nn.Module):
+    """models.py:126-269."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        seq = OrderedDict()
+        cin, n_pool = 3, 0
+        for idx, (cout, k, after) in enumerate(_DARKNET_PLAN, start=1):
+            _cbl(seq, idx, cin, cout, k, 1, k // 2, bias=False, momentum=0.01)
+            if after == 'M':
+                n_pool += 1
+                seq['maxpool_%d' % n_pool] = HipMaxPool2()
+            else:
+                seq['drop_%d' % idx] = nn.Dropout(params.dropout)
+            cin = cout
+        seq['conv_19'] = HipConv2d(1024, 5 * params.n_boxes + params.n_classes, 1, bias=False)
+        self.model = FusedBackbone(seq)
+
+    def forward(self, x):
+        out = self.model(x)                                            # NHWC == the reference's permute(0,2,3,1)
+        return ops.yolo_head(out, 5 * self.params.n_boxes, self.params.n_classes)
+
+    def load_weights(self, weights_dir, n_load_layer):
+        """models.py:238-269: TF-style npz ('<idx>-<scope>/<name>:0', HWIO kernels) into the first layers."""
+        import numpy as np
+        names = {'kernel:0': ('conv', 'weight'), 'biases:0': ('bn', 'bias'), 'gamma:0': ('bn', 'weight'),
+                 'moving_mean:0': ('bn', 'running_mean'), 'moving_variance:0': ('bn', 'running_var')}
+        state = self.state_dict()
+        for key, v in np.load(weights_dir).items():
+            index, layer = key.split('-')
+            index = int(index) + 1
+            if index > n_load_layer:
+                continue
+            kind, pname = names[layer.split('/')[1]]
+            t = torch.from_numpy(v)
+            if kind == 'conv':
+                t = t.permute(3, 2, 0, 1)
+            state['model.%s_%d.%s' % (kind, index, pname)] = t
+        self.load_state_dict(state)
+
+
+def _darkcaps_backbone():
+    seq = OrderedDict()
+    _cbl(seq, 1, 3, 128, 3, 1, 1)
+    _cbl(seq, 2, 128, 256, 3, 1, 1)
+    _cbl(seq, 3, 256, 64, 4, 2, 1)
+    _cbl(seq, 4, 64, 128, 4, 2, 1)
+    _cbl(seq, 5, 128, 256, 4, 2, 1)
+    return FusedBackbone(seq)
+
+
+class DarkCapsuleNet(nn.Module):
+    """models.py:340-400.  The cell gather (393-398) is folded into the routing kernel's loads."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.conv = _darkcaps_backbone()
+        self.traffic_sign_capsules = CapsuleLayer(params, n_caps=1, n_nodes=16 * 32, in_C=8, out_C=5,
+                                                  n_iter=getattr(params, 'n_iter', 3))
+        self.decoder = Decoder()            # unused in forward, like the reference
+
+    def forward(self, x):
+        B, g = x.shape[0], self.params.n_grid
+        if x.shape[2] != 32 * g or x.shape[3] != 32 * g:
+            raise ValueError('DarkCapsuleNet needs H = W = 32*n_grid (models.py:393); got %s, n_grid=%d'
+                             % (tuple(x.shape), g))
+        feat = self.conv(x)                                            # [B,4g,4g,256] NHWC
+        v = self.traffic_sign_capsules(feat, gather_g=g, gather_B=B)   # [B,g,g,1,5]
+        return v.view(B, g, g, 5)
+
+
+class DarkCapsuleNet3(nn.Module):
+    """models.py:403-463."""
+
+    def __init__(self, params):
+        super().__init__()
+        self.params = params
+        self.conv = _darkcaps_backbone()
+        self.traffic_sign_capsules = CapsuleLayer(params, n_caps=params.n_classes, n_nodes=16 * 32, in_C=8,
+                                                  out_C=5 + 16, n_iter=getattr(params, 'n_iter', 3))
+        self.decoder = Decoder()
+
+    def forward(self, x):
+        B, g = x.shape[0], self.params.n_grid
+        feat = self.conv(x)
+        return self.traffic_sign_capsules(feat, gather_g=g, gather_B=B)   # [B,g,g,C,21]
+
+
+class ConvNet(nn.Module):
+    """models.py:22-43: the plain-torch CNN baseline (not a kernel target)."""
+
+    def __init__(self, params):
+        super().__init__()
+
+        class Flatten(nn.Module):
+            def forward(self, x):
+                return x.view(x.size(0), -1)
+        self.cnn = nn.Sequential(
+            nn.Conv2d(3, 64, 3, padding=1), nn.BatchNorm2d(64), nn.LeakyReLU(inplace=True), nn.Dropout(params.dropout),
+            nn.Conv2d(64, 128, 3, padding=1), nn.BatchNorm2d(128), nn.LeakyReLU(inplace=True),
+            nn.Dropout(params.dropout), nn.MaxPool2d(2), Flatten(), nn.Linear(128 * 16 * 16, 128), nn.ReLU(),
+            nn.Linear(128, params.n_classes))
+
+    def forward(self, x):
+        return self.cnn(x)

@@ -1,0 +1,537 @@
+"""torch.autograd wrappers over the C-ABI kernels (include/capsyolo_hip.h).
+
+PyTorch supplies device memory, the current HIP stream and the autograd graph; every
+arithmetic step below is a call into libcapsyolo_hip.so.  All activations are NHWC fp32
+tensors ([B,H,W,C], plain contiguous).  No function here has a CPU or ATen fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ConvGemm, ConvWgrad, RoutingBwd, RoutingFwd, call, query
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _f32(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise _lib.HipExtensionError('%s must be a float32 tensor on the GPU (got %s on %s); there is no CPU fallback'
+                                     % (name, t.dtype, t.device))
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _empty(shape, like, dtype=torch.float32):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+def _x_geometry(x, nchw):
+    if nchw:
+        B, Cin, Hi, Wi = x.shape
+        return B, Hi, Wi, Cin, (Cin * Hi * Wi, Wi, 1, Hi * Wi)
+    B, Hi, Wi, Cin = x.shape
+    return B, Hi, Wi, Cin, (Hi * Wi * Cin, Wi * Cin, Cin, 1)
+
+
+def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False):
+    """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
+    B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
+    Cout = weight.shape[0]
+    Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    st = _stream()
+    wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
+    call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, k, k, 0, 0, 1, 0, st)
+    z = _empty((B, Ho, Wo, Cout), x)
+    a = ConvGemm(X=x.data_ptr(), Wp=wp.data_ptr(), Y=z.data_ptr(),
+                 bias=bias.data_ptr() if bias is not None else None,
+                 stats=stats.data_ptr() if stats is not None else None,
+                 xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
+                 TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1,
+                 Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=1 if relu else 0)
+    call('cy_conv_gemm', C.byref(a), st)
+    return z
+
+
+def conv_dgrad(dz, weight, in_shape, k, stride, pad):
+    """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride."""
+    B, Hi, Wi, Cin = in_shape
+    _, Ho, Wo, Cout = dz.shape
+    st = _stream()
+    dx = _empty((B, Hi, Wi, Cin), dz)
+    covered = True
+    wp = _empty((query('cy_conv_packed_floats', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dz)
+    for py in range(stride):
+        kh0 = (py + pad) % stride
+        TH = len(range(kh0, k, stride))
+        for px in range(stride):
+            kw0 = (px + pad) % stride
+            TW = len(range(kw0, k, stride))
+            Hv, Wv = (Hi - py + stride - 1) // stride, (Wi - px + stride - 1) // stride
+            if Hv <= 0 or Wv <= 0:
+                continue
+            if TH == 0 or TW == 0:
+                covered = False
+                continue
+            call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, TH, TW, kh0, kw0, stride, 1, st)
+            a = ConvGemm(X=dz.data_ptr(), Wp=wp.data_ptr(), Y=dx.data_ptr(), bias=None, stats=None,
+                         xs_b=Ho * Wo * Cout, xs_y=Wo * Cout, xs_x=Cout, xs_c=1, B=B, Hi=Ho, Wi=Wo, Cin=Cout,
+                         Ho=Hv, Wo=Wv, N=Cin, TH=TH, TW=TW, in_stride=1,
+                         dy0=(py + pad - kh0) // stride, dx0=(px + pad - kw0) // stride, dstep=-1,
+                         Hy=Hi, Wy=Wi, out_stride=stride, out_oy=py, out_ox=px, act=0)
+            call('cy_conv_gemm', C.byref(a), st)
+    if not covered:
+        raise _lib.HipExtensionError('conv_dgrad: kernel %d / stride %d leaves input pixels without taps' % (k, stride))
+    return dx
+
+
+def conv_wgrad(x, dz, k, stride, pad, nchw=False):
+    B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
+    _, Ho, Wo, Cout = dz.shape
+    st = _stream()
+    dW = _empty((Cout, Cin, k, k), dz)
+    a = ConvWgrad(X=x.data_ptr(), dZ=dz.data_ptr(), dW=dW.data_ptr(), slabs=None,
+                  xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
+                  KH=k, KW=k, stride=stride, pad=pad)
+    ws = _empty((query('cy_conv_wgrad_ws_floats', C.byref(a)),), dz)
+    a.slabs = ws.data_ptr()
+    call('cy_conv_wgrad', C.byref(a), st)
+    return dW
+
+
+class ConvBlockCfg(object):
+    """Static description of one conv (+BatchNorm) (+activation) block."""
+
+    def __init__(self, k, stride, pad, nchw_in=False, bn=None, slope=None):
+        self.k, self.stride, self.pad, self.nchw_in = k, stride, pad, nchw_in
+        self.bn = bn            # module with running_mean / running_var / momentum / eps / training, or None
+        self.slope = slope      # None: no activation; 0.0: ReLU; else LeakyReLU slope
+
+
+class _ConvBlock(torch.autograd.Function):
+    """conv -> [BatchNorm (batch statistics from the conv epilogue)] -> [Leaky]ReLU, saving only x and z."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, cfg):
+        x = _f32(x, 'conv input')
+        weight = _f32(weight, 'conv weight')
+        st = _stream()
+        N = weight.shape[0]
+        bn = cfg.bn
+        ctx.cfg, ctx.has_bias, ctx.bn_train = cfg, bias is not None, False
+        if bn is None:
+            relu = cfg.slope is not None and cfg.slope == 0.0
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, relu)
+            out = z
+            if cfg.slope is not None and not relu:
+                out = torch.empty_like(z)
+                call('cy_affine_act', _ptr(z), _ptr(out), None, None, float(cfg.slope), z.numel() // N, N, st)
+            ctx.save_for_backward(x, weight, z)
+            return out
+        scale, shift = _empty((N,), x), _empty((N,), x)
+        mean, invstd = _empty((N,), x), _empty((N,), x)
+        if bn.training:
+            stats = torch.zeros((N, 2), dtype=torch.float64, device=x.device)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False)
+            P = z.numel() // N
+            call('cy_bn_finalize', _ptr(stats), P, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
+                 _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean),
+                 _ptr(invstd), N, st)
+            bn.num_batches_tracked += 1
+            ctx.bn_train = True
+        else:
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False)
+            P = z.numel() // N
+            call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
+                 float(bn.eps), _ptr(scale), _ptr(shift), N, st)
+        out = torch.empty_like(z)
+        slope = 1.0 if cfg.slope is None else float(cfg.slope)
+        call('cy_affine_act', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), slope, P, N, st)
+        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        cfg = ctx.cfg
+        da = _f32(da, 'grad')
+        st = _stream()
+        saved = ctx.saved_tensors
+        x, weight, z = saved[0], saved[1], saved[2]
+        N = weight.shape[0]
+        P = z.numel() // N
+        dgamma = dbeta = dbias = None
+        if cfg.bn is None:
+            if cfg.slope is not None:
+                dz = torch.empty_like(z)
+                call('cy_act_bwd', _ptr(z), _ptr(da), _ptr(dz), float(cfg.slope), z.numel(), st)
+            else:
+                dz = da
+            if ctx.has_bias:
+                dbias = _empty((N,), z)
+                call('cy_channel_sum', _ptr(dz), _ptr(dbias), P, N, st)
+        else:
+            if not ctx.bn_train:
+                raise _lib.HipExtensionError('backward through an eval-mode BatchNorm block is not implemented')
+            scale, shift, mean, invstd, gamma = saved[3:8]
+            slope = 1.0 if cfg.slope is None else float(cfg.slope)
+            red = _empty((N, 2), z, torch.float64)
+            call('cy_bn_bwd_reduce', _ptr(z), _ptr(da), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), slope,
+                 _ptr(red), P, N, st)
+            dz = torch.empty_like(z)
+            dgamma, dbeta = _empty((N,), z), _empty((N,), z)
+            call('cy_bn_bwd_apply', _ptr(z), _ptr(da), _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                 _ptr(gamma), slope, _ptr(red), _ptr(dgamma), _ptr(dbeta), P, N, st)
+            if ctx.has_bias:
+                # a bias in front of BatchNorm has an analytically zero gradient: sum(dz) == 0
+                dbias = torch.zeros((N,), dtype=torch.float32, device=z.device)
+        dW = conv_wgrad(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cfg.nchw_in:
+                raise _lib.HipExtensionError('input gradient of an NCHW-input convolution is not implemented')
+            dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad)
+        return dx, dW, dbias, dgamma, dbeta, None
+
+
+def conv_block(x, weight, bias, gamma, beta, cfg):
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, cfg)
+
+
+# ------------------------------------------------------------------------------------------------ routing
+class _Routing(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, u, W, n_iter, gather_g, gather_B):
+        u, W = _f32(u, 'capsule input'), _f32(W, 'route_weights')
+        _, N, Cc, Din, Dout = W.shape
+        if gather_g:
+            R = gather_g * gather_g * gather_B
+            out_shape = (gather_B, gather_g, gather_g, Cc, Dout)
+        else:
+            R = u.shape[0]
+            out_shape = (R, Cc, Dout)
+        v = _empty(out_shape, u)
+        s_hist = _empty((n_iter, R, Cc, Dout), u)
+        a = RoutingFwd(u=u.data_ptr(), W=W.data_ptr(), v_out=v.data_ptr(), s_hist=s_hist.data_ptr(), R=R, N=N, C=Cc,
+                       Din=Din, Dout=Dout, n_iter=n_iter, gather_g=gather_g, gather_B=gather_B)
+        call('cy_routing_fwd', C.byref(a), _stream())
+        ctx.save_for_backward(u, W, s_hist)
+        ctx.dims = (R, N, Cc, Din, Dout, n_iter, gather_g, gather_B)
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        u, W, s_hist = ctx.saved_tensors
+        R, N, Cc, Din, Dout, n_iter, g, gB = ctx.dims
+        dv = _f32(dv, 'grad')
+        du, dW = torch.empty_like(u), torch.empty_like(W)
+        a = RoutingBwd(u=u.data_ptr(), W=W.data_ptr(), s_hist=s_hist.data_ptr(), dv=dv.data_ptr(), du=du.data_ptr(),
+                       dW=dW.data_ptr(), ws=None, R=R, N=N, C=Cc, Din=Din, Dout=Dout, n_iter=n_iter, gather_g=g,
+                       gather_B=gB)
+        ws = _empty((query('cy_routing_bwd_ws_floats', C.byref(a)),), u)
+        a.ws = ws.data_ptr()
+        call('cy_routing_bwd', C.byref(a), _stream())
+        return du, dW, None, None, None
+
+
+def routing(u, W, n_iter=3, gather_g=0, gather_B=0):
+    """u [R,N,Din] (or the NHWC feature map [B,4g,4g,256] with gather_g=g), W [1,N,C,Din,Dout] -> v."""
+    return _Routing.apply(u, W, int(n_iter), int(gather_g), int(gather_B))
+
+
+# ------------------------------------------------------------------------------------------------ small vector ops
+class _Rows(torch.autograd.Function):
+    """squash / length over the last dimension."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = _f32(x)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        st = _stream()
+        ctx.kind = kind
+        if kind == 'squash':
+            y = torch.empty_like(x)
+            call('cy_squash_fwd', _ptr(x), _ptr(y), rows, D, st)
+            ctx.save_for_backward(x)
+        else:
+            y = _empty(x.shape[:-1], x)
+            call('cy_length_fwd', _ptr(x), _ptr(y), rows, D, st)
+            ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _f32(dy)
+        st = _stream()
+        x = ctx.saved_tensors[0]
+        D = x.shape[-1]
+        rows = x.numel() // D
+        dx = torch.empty_like(x)
+        if ctx.kind == 'squash':
+            call('cy_squash_bwd', _ptr(x), _ptr(dy), _ptr(dx), rows, D, st)
+        else:
+            call('cy_length_bwd', _ptr(x), _ptr(ctx.saved_tensors[1]), _ptr(dy), _ptr(dx), rows, D, st)
+        return dx, None
+
+
+def squash(x):
+    return _Rows.apply(x, 'squash')
+
+
+def length(x):
+    return _Rows.apply(x, 'length')
+
+
+class _Permute4(torch.autograd.Function):
+    """out[b][i1][i2][i3] = in[b*sb + i1*s1 + i2*s2 + i3*s3]; backward is the inverse scatter."""
+
+    @staticmethod
+    def forward(ctx, x, nb, dims, strides):
+        x = _f32(x)
+        out = _empty((nb,) + tuple(dims), x)
+        call('cy_permute4', _ptr(x), _ptr(out), nb, dims[0], dims[1], dims[2], strides[0], strides[1], strides[2],
+             strides[3], 0, _stream())
+        ctx.args = (nb, dims, strides, tuple(x.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        nb, dims, strides, xshape = ctx.args
+        dout = _f32(dout)
+        dx = _empty(xshape, dout)
+        call('cy_permute4', _ptr(dout), _ptr(dx), nb, dims[0], dims[1], dims[2], strides[0], strides[1], strides[2],
+             strides[3], 1, _stream())
+        return dx, None, None, None
+
+
+def nchw_to_nhwc(x):
+    B, Cc, H, W = x.shape
+    return _Permute4.apply(x, B, (H, W, Cc), (Cc * H * W, W, 1, H * W))
+
+
+def nhwc_to_nchw(x):
+    B, H, W, Cc = x.shape
+    return _Permute4.apply(x, B, (Cc, H, W), (H * W * Cc, 1, W * Cc, Cc))
+
+
+def primary_caps_rows(z, n_caps):
+    """conv output [B,h,w,(o,cap)] -> capsule rows [B, o*h*w + y*w + x, cap] (models.py:81: view(B,-1,1) + cat)."""
+    B, H, W, Cc = z.shape
+    O = Cc // n_caps
+    out = _Permute4.apply(z, B, (O, H * W, n_caps), (H * W * Cc, n_caps, Cc, 1))
+    return out.view(B, O * H * W, n_caps)
+
+
+class _MaxPool2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        y = _empty((B, H // 2, W // 2, Cc), x)
+        idx = _empty((B, H // 2, W // 2, Cc), x, torch.uint8)
+        call('cy_maxpool2_fwd', _ptr(x), _ptr(y), _ptr(idx), B, H // 2, W // 2, Cc, _stream())
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        B, H, W, Cc = ctx.shape
+        dy = _f32(dy)
+        dx = _empty((B, H, W, Cc), dy) if (H % 2 == 0 and W % 2 == 0) else torch.zeros((B, H, W, Cc), device=dy.device)
+        call('cy_maxpool2_bwd', _ptr(dy), _ptr(idx), _ptr(dx), B, H // 2, W // 2, Cc, _stream())
+        return dx
+
+
+def maxpool2(x):
+    return _MaxPool2.apply(x)
+
+
+class _Upsample(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, f):
+        x = _f32(x)
+        B, H, W, Cc = x.shape
+        y = _empty((B, H * f, W * f, Cc), x)
+        call('cy_upsample_fwd', _ptr(x), _ptr(y), B, H, W, Cc, f, _stream())
+        ctx.args = (B, H, W, Cc, f)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc, f = ctx.args
+        dy = _f32(dy)
+        dx = _empty((B, H, W, Cc), dy)
+        call('cy_upsample_bwd', _ptr(dy), _ptr(dx), B, H, W, Cc, f, _stream())
+        return dx, None
+
+
+def upsample_nearest(x, f):
+    return _Upsample.apply(x, int(f))
+
+
+class _Tanh(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        call('cy_tanh_fwd', _ptr(x), _ptr(y), x.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = _f32(dy)
+        dx = torch.empty_like(y)
+        call('cy_tanh_bwd', _ptr(y), _ptr(dy), _ptr(dx), y.numel(), _stream())
+        return dx
+
+
+def tanh(x):
+    return _Tanh.apply(x)
+
+
+class _YoloHead(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, split, n_classes):
+        x = _f32(x)
+        y = torch.empty_like(x)
+        cells = x.numel() // (split + n_classes)
+        call('cy_yolo_head_fwd', _ptr(x), _ptr(y), cells, split, n_classes, _stream())
+        ctx.save_for_backward(y)
+        ctx.args = (cells, split, n_classes)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        cells, split, n_classes = ctx.args
+        dy = _f32(dy)
+        dx = torch.empty_like(y)
+        call('cy_yolo_head_bwd', _ptr(y), _ptr(dy), _ptr(dx), cells, split, n_classes, _stream())
+        return dx, None, None
+
+
+def yolo_head(x, split, n_classes):
+    return _YoloHead.apply(x, int(split), int(n_classes))
+
+
+class _PickCapsule(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, caps, y):
+        caps = _f32(caps)
+        B, Cc, D = caps.shape
+        y = y.to(torch.int64).contiguous()
+        out = _empty((B, D), caps)
+        call('cy_pick_capsule', _ptr(caps), _ptr(y), _ptr(out), B, Cc, D, 0, _stream())
+        ctx.save_for_backward(y)
+        ctx.shape = (B, Cc, D)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (y,) = ctx.saved_tensors
+        B, Cc, D = ctx.shape
+        dout = _f32(dout)
+        dcaps = _empty((B, Cc, D), dout)
+        call('cy_pick_capsule', _ptr(dout), _ptr(y), _ptr(dcaps), B, Cc, D, 1, _stream())
+        return dcaps, None
+
+
+def pick_capsule(caps, y):
+    return _PickCapsule.apply(caps, y)
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def _scaled(grad, gout):
+    out = torch.empty_like(grad)
+    gout = gout.to(torch.float32).contiguous()
+    call('cy_scale_by_device_scalar', _ptr(grad), _ptr(gout), _ptr(out), grad.numel(), _stream())
+    return out
+
+
+class _DarkCapsuleLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, caps, y):
+        caps = _f32(caps, 'caps')
+        if not (y.is_cuda and y.dtype == torch.float64):
+            y = y.to(device=caps.device, dtype=torch.float64)
+        y = y.contiguous()
+        B = caps.shape[0]
+        cells = caps.numel() // (5 * B)
+        loss, dcaps = _empty((), caps), torch.empty_like(caps)
+        call('cy_darkcapsule_loss', _ptr(caps), _ptr(y), y.shape[-1], _ptr(loss), _ptr(dcaps), B, cells, _stream())
+        ctx.save_for_backward(dcaps)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        return _scaled(ctx.saved_tensors[0], gout), None
+
+
+class _CapsuleLoss(torch.autograd.Function):
+    """margin loss (+ recon_coef * sum (x - recon)^2), all divided by B."""
+
+    @staticmethod
+    def forward(ctx, scores, y, x, recon, coef):
+        scores = _f32(scores, 'scores')
+        B, Cc = scores.shape
+        y = y.to(torch.int64).contiguous()
+        st = _stream()
+        loss, dscores = _empty((), scores), torch.empty_like(scores)
+        call('cy_margin_loss', _ptr(scores), _ptr(y), _ptr(loss), _ptr(dscores), B, Cc, st)
+        if recon is not None:
+            x, recon = _f32(x, 'x'), _f32(recon, 'recon')
+            drecon = torch.empty_like(recon)
+            call('cy_recon_loss_add', _ptr(x), _ptr(recon), float(coef) / B, _ptr(loss), _ptr(drecon), recon.numel(), st)
+            ctx.save_for_backward(dscores, drecon)
+        else:
+            ctx.save_for_backward(dscores)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        saved = ctx.saved_tensors
+        drecon = _scaled(saved[1], gout) if len(saved) > 1 else None
+        return _scaled(saved[0], gout), None, None, drecon, None
+
+
+class _DarkLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y_pred, y_true, nb, n_classes, l_coord, l_noobj, img):
+        y_pred = _f32(y_pred, 'y_pred')
+        if not (y_true.is_cuda and y_true.dtype == torch.float64):
+            y_true = y_true.to(device=y_pred.device, dtype=torch.float64)
+        y_true = y_true.contiguous()
+        B, g = y_pred.shape[0], y_pred.shape[1]
+        loss, avg_iou = _empty((), y_pred), _empty((), y_pred)
+        dpred = torch.empty_like(y_pred)
+        call('cy_dark_loss', _ptr(y_pred), _ptr(y_true), _ptr(loss), _ptr(avg_iou), _ptr(dpred), B, g, nb, n_classes,
+             float(l_coord), float(l_noobj), float(img), _stream())
+        ctx.save_for_backward(dpred)
+        ctx.mark_non_differentiable(avg_iou)
+        return loss, avg_iou
+
+    @staticmethod
+    def backward(ctx, gout, _g_iou):
+        return _scaled(ctx.saved_tensors[0], gout), None, None, None, None, None, None
+
+
+def darkcapsule_loss_fn(caps, y):
+    return _DarkCapsuleLoss.apply(caps, y)
+
+
+def capsule_loss_fn(scores, y, x=None, recon=None, coef=0.0):
+    return _CapsuleLoss.apply(scores, y, x, recon, coef)
+
+
+def dark_loss_fn(y_pred, y_true, nb, n_classes, l_coord, l_noobj, img):
+    return _DarkLoss.apply(y_pred, y_true, nb, n_classes, l_coord, l_noobj, img)

@@ -1,0 +1,60 @@
+"""torch.optim.Adam replacement: every parameter updated by ONE multi-tensor HIP launch per step
+(csrc/adam.hip).  Same hyper-parameters, state layout ('step', 'exp_avg', 'exp_avg_sq') and update
+formula as torch.optim.Adam (main.py:280), so optimizer checkpoints interchange."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import call
+
+_CHUNK = 16384
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._plan_key, self._plan = None, None
+
+    def _build_plan(self, entries, device):
+        table = np.zeros((len(entries), 5), dtype=np.int64)
+        blocks = []
+        for k, (p, g, m, v) in enumerate(entries):
+            table[k] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel())
+            blocks.extend((k, c) for c in range((p.numel() + _CHUNK - 1) // _CHUNK))
+        bm = np.asarray(blocks, dtype=np.int32).reshape(-1, 2)
+        return (torch.from_numpy(table).to(device), torch.from_numpy(bm).to(device), len(blocks))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        for group in self.param_groups:
+            entries, steps = [], set()
+            for p in group['params']:
+                if p.grad is None:
+                    continue
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
+                    raise RuntimeError('capsyolo_amd.optim.Adam needs contiguous float32 GPU parameters')
+                st = self.state[p]
+                if len(st) == 0:
+                    st['step'] = 0
+                    st['exp_avg'] = torch.zeros_like(p)
+                    st['exp_avg_sq'] = torch.zeros_like(p)
+                st['step'] = int(st['step']) + 1
+                steps.add(st['step'])
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                entries.append((p, g, st['exp_avg'], st['exp_avg_sq']))
+            if not entries:
+                continue
+            if len(steps) != 1:
+                raise RuntimeError('parameters of one group must share their step count')
+            t = steps.pop()
+            key = tuple(x.data_ptr() for e in entries for x in e)
+            if key != self._plan_key:
+                self._plan, self._plan_key = self._build_plan(entries, entries[0][0].device), key
+            table, bm, nblocks = self._plan
+            b1, b2 = group['betas']
+            call('cy_adam_multi', C.c_void_p(table.data_ptr()), C.c_void_p(bm.data_ptr()), nblocks, _CHUNK,
+                 float(group['lr']), float(b1), float(b2), float(group['eps']), float(1.0 - b1 ** t),
+                 float(1.0 - b2 ** t), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        return loss

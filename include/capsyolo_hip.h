@@ -1,0 +1,183 @@
+/* capsyolo_hip.h -- C-ABI of libcapsyolo_hip.so (hand-written gfx950 kernels).
+ *
+ * Drop-in boundary for the training hot path of
+ * Cranial-XIX/cs231-capsule-yolo-traffic-sign-detection.  The reference has no FFI
+ * (all arithmetic is torch ATen calls); each entry point below replaces the ATen
+ * work issued by the cited reference lines.  Conventions for EVERY function:
+ *   - plain C types only; every pointer is a DEVICE pointer owned by the caller
+ *     (the PyTorch caching allocator), valid on `stream`; nothing is allocated,
+ *     freed or retained by the library;
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous;
+ *   - re-entrant, no mutable global state (forward is called from the Python
+ *     main thread, backward from the autograd engine thread);
+ *   - returns 0 on success, otherwise a non-zero code (hipError_t for runtime
+ *     errors, CY_EINVAL for rejected arguments); capsyolo_last_error() gives
+ *     the text for the calling thread.
+ * Activations are NHWC fp32 unless a stride set says otherwise.
+ */
+#ifndef CAPSYOLO_HIP_H
+#define CAPSYOLO_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CY_EINVAL 10001
+
+const char* capsyolo_last_error(void);
+int capsyolo_abi_version(void);
+
+/* ------------------------------------------------------------------ convolution as implicit GEMM
+ * Replaces nn.Conv2d forward / input-gradient / weight-gradient:
+ * models.py:90 (conv1), 60-62 (primary capsule convs), 98-110 (decoder convs),
+ * 132-223 (DarkNet), 347-363 (DarkCapsuleNet backbone).
+ *
+ * One description drives forward and input-gradient: a "virtual output grid"
+ * [B,Ho,Wo] of pixels, each the sum over TH x TW taps of a Cin-vector of X times
+ * a [Cin x N] weight slice:
+ *   iy = oy*in_stride + dy0 + a*dstep,  ix = ox*in_stride + dx0 + b*dstep   (zero outside X)
+ *   Y[b, oy*out_stride+out_oy, ox*out_stride+out_ox, n] = act(sum + bias[n])
+ * X is addressed through element strides (xs_*), so NCHW inputs work (Cin%32 != 0 path).
+ */
+typedef struct {
+  const float* X; const float* Wp; float* Y; const float* bias; double* stats;
+  long long xs_b, xs_y, xs_x, xs_c;
+  int B, Hi, Wi, Cin;
+  int Ho, Wo, N;
+  int TH, TW, in_stride, dy0, dx0, dstep;
+  int Hy, Wy, out_stride, out_oy, out_ox;
+  int act;            /* 0 none, 1 ReLU */
+} cy_conv_gemm_t;
+
+/* number of floats of a packed-weight buffer for (K = TH*TW*Cin, N) */
+long long cy_conv_packed_floats(int K, int N);
+/* pack PyTorch-layout weights W[Cout][Cin][KH][KW] for the forward GEMM of a (sub)set of taps:
+ * tap (a,b) uses kernel element (kh0 + a*kstep, kw0 + b*kstep);  transpose=1 packs the
+ * input-gradient operand (rows = (tap, cout), columns = cin). */
+int cy_conv_pack_weights(const float* W, float* Wp, int Cout, int Cin, int KH, int KW,
+                         int TH, int TW, int kh0, int kw0, int kstep, int transpose, void* stream);
+/* Y = conv(X) (+bias, +act); if stats != NULL also accumulates per-channel sum / sum-of-squares
+ * of the pre-activation output into stats[N][2] (double), which the caller zeroed. */
+int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream);
+
+/* weight gradient: dW[Cout][Cin][KH][KW] = sum over pixels of X-patch (x) dZ.
+ * slabs: workspace of cy_conv_wgrad_ws_floats() floats.  dZ is NHWC [B,Ho,Wo,N] contiguous. */
+typedef struct {
+  const float* X; const float* dZ; float* dW; float* slabs;
+  long long xs_b, xs_y, xs_x, xs_c;
+  int B, Hi, Wi, Cin;
+  int Ho, Wo, N;
+  int KH, KW, stride, pad;
+} cy_conv_wgrad_t;
+long long cy_conv_wgrad_ws_floats(const cy_conv_wgrad_t* a);
+int cy_conv_wgrad(const cy_conv_wgrad_t* a, void* stream);
+
+/* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */
+int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream);
+
+/* ------------------------------------------------------------------ BatchNorm2d (+LeakyReLU), NHWC
+ * Replaces nn.BatchNorm2d + nn.LeakyReLU in training and eval mode (models.py:132-223, 347-365). */
+/* stats[N][2] (sum, sumsq from cy_conv_gemm) -> scale/shift (gamma*invstd, beta-mean*scale),
+ * mean, invstd; updates running_mean/var with `momentum` (unbiased variance), as torch does. */
+int cy_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, float momentum, float eps,
+                   float* scale, float* shift, float* mean, float* invstd, int N, void* stream);
+/* eval mode: scale/shift from the running statistics */
+int cy_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, float eps, float* scale, float* shift, int N, void* stream);
+/* A = lrelu(Z*scale + shift), negative slope `slope` (1.0 = identity, 0.0 = ReLU); scale/shift may be NULL */
+int cy_affine_act(const float* Z, float* A, const float* scale, const float* shift, float slope,
+                  long long P, int N, void* stream);
+/* backward, pass 1: red[N][2] += (sum dYhat, sum dYhat*xhat), dYhat = dA * lrelu'(Z*scale+shift) */
+int cy_bn_bwd_reduce(const float* Z, const float* dA, const float* scale, const float* shift,
+                     const float* mean, const float* invstd, float slope, double* red,
+                     long long P, int N, void* stream);
+/* backward, pass 2: dZ = gamma*invstd*(dYhat - mean(dYhat) - xhat*mean(dYhat*xhat)); dgamma, dbeta written */
+int cy_bn_bwd_apply(const float* Z, const float* dA, float* dZ, const float* scale, const float* shift,
+                    const float* mean, const float* invstd, const float* gamma, float slope,
+                    const double* red, float* dgamma, float* dbeta, long long P, int N, void* stream);
+/* activation-only backward: dZ = dA * act'(Z)  (ReLU convs without BN) */
+int cy_act_bwd(const float* Z, const float* dA, float* dZ, float slope, long long n, void* stream);
+
+/* ------------------------------------------------------------------ capsule routing
+ * Replaces CapsuleLayer.forward, routing branch (models.py:70-79), all n_iter iterations in one
+ * launch, and its autograd backward.  u rows are either contiguous [R][N*Din] (gather_g == 0) or
+ * read straight from the NHWC feature map [B][4g][4g][256] through the DarkCapsuleNet "cell
+ * gather" (models.py:393-398; row = k*B + b).  W is route_weights [N][C][Din][Dout].
+ * v_out [R][C][Dout] in row order, or, with the cell gather, [B][g*g][C][Dout] (the layout that
+ * view(g,g,B,.).permute(2,0,1,3), models.py:399, presents); dv of the backward uses the same
+ * layout.  s_hist [n_iter][R][C][Dout] keeps every iteration's pre-squash sums for the backward. */
+typedef struct {
+  const float* u; const float* W; float* v_out; float* s_hist;
+  int R, N, C, Din, Dout, n_iter;
+  int gather_g, gather_B;
+} cy_routing_fwd_t;
+int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream);
+
+typedef struct {
+  const float* u; const float* W; const float* s_hist; const float* dv;   /* dv [R][C][Dout] */
+  float* du;            /* same addressing as u (contiguous rows or NHWC feature-map gradient) */
+  float* dW;            /* [N][C][Din][Dout], overwritten */
+  float* ws;            /* workspace, cy_routing_bwd_ws_floats() floats */
+  int R, N, C, Din, Dout, n_iter;
+  int gather_g, gather_B;
+} cy_routing_bwd_t;
+long long cy_routing_bwd_ws_floats(const cy_routing_bwd_t* a);
+int cy_routing_bwd(const cy_routing_bwd_t* a, void* stream);
+
+/* squash over the last dim (models.py:64-67), rows of D floats; and its backward */
+int cy_squash_fwd(const float* s, float* v, long long rows, int D, void* stream);
+int cy_squash_bwd(const float* s, const float* dv, float* ds, long long rows, int D, void* stream);
+/* capsule length (x**2).sum(-1)**0.5 (models.py:117) and backward */
+int cy_length_fwd(const float* v, float* len, long long rows, int D, void* stream);
+int cy_length_bwd(const float* v, const float* len, const float* dlen, float* dv, long long rows, int D, void* stream);
+
+/* ------------------------------------------------------------------ losses (forward value + input gradient in one launch)
+ * loss_out: one float, overwritten.  Gradients are d(loss)/d(input) for an upstream gradient of 1. */
+/* loss_fns.py:187-204 + utils.py:69-85; caps [B,g,g,5] fp32, y [B,g,g,5+C] fp64 */
+int cy_darkcapsule_loss(const float* caps, const double* y, int ystride, float* loss_out, float* dcaps,
+                        int B, int cells, void* stream);
+/* loss_fns.py:11-23 margin part; scores [B,C], labels int64 */
+int cy_margin_loss(const float* scores, const long long* y, float* loss_out, float* dscores,
+                   int B, int C, void* stream);
+/* coef * sum((x-recon)^2) / B added into loss_out (loss_fns.py:19-21); drecon written */
+int cy_recon_loss_add(const float* x, const float* recon, float coef_over_B, float* loss_out, float* drecon,
+                      long long n, void* stream);
+/* loss_fns.py:60-142 (dense form); y_pred [B,g,g,5nb+C] fp32, y_true [B,g,g,5+C] fp64; avg_iou_out one float */
+int cy_dark_loss(const float* y_pred, const double* y_true, float* loss_out, float* avg_iou_out, float* dpred,
+                 int B, int g, int nb, int C, float l_coord, float l_noobj, float img_size, void* stream);
+/* out = in * (*scalar)  (backward of a scalar loss with upstream gradient on the device) */
+int cy_scale_by_device_scalar(const float* in, const float* scalar, float* out, long long n, void* stream);
+
+/* ------------------------------------------------------------------ data movement / elementwise around the path
+ * Layout permutes standing in for the reference's view/permute/cat glue (models.py:8-19, 80-82):
+ * out[b][i1][i2][i3] (contiguous, dims nb x d1 x d2 x d3) = in[b*sb + i1*s1 + i2*s2 + i3*s3];
+ * scatter=1 runs the inverse (in is contiguous, out is strided): the backward of the gather. */
+int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,
+                long long s2, long long s3, int scatter, void* stream);
+/* nn.MaxPool2d(2) on NHWC (models.py:135-195): x [B,2Ho,2Wo,C] -> y [B,Ho,Wo,C]; idx keeps the argmax (0..3) */
+int cy_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int B, int Ho, int Wo, int C, void* stream);
+int cy_maxpool2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int Ho, int Wo, int C, void* stream);
+/* nn.Upsample (nearest, integer factor f; models.py:99-105) on NHWC and its backward */
+int cy_upsample_fwd(const float* x, float* y, int B, int Hi, int Wi, int C, int f, void* stream);
+int cy_upsample_bwd(const float* dy, float* dx, int B, int Hi, int Wi, int C, int f, void* stream);
+int cy_tanh_fwd(const float* x, float* y, long long n, void* stream);
+int cy_tanh_bwd(const float* y, const float* dy, float* dx, long long n, void* stream);
+/* DarkNet head (models.py:226-236): sigmoid on the first `split` values of each cell, softmax on the other C */
+int cy_yolo_head_fwd(const float* x, float* y, long long cells, int split, int C, void* stream);
+int cy_yolo_head_bwd(const float* y, const float* dy, float* dx, long long cells, int split, int C, void* stream);
+/* torch.gather of the labelled capsule (models.py:122): backward=0: out[B][D] = caps[b][y[b]][:];
+ * backward=1: caps is d(out) [B][D], out = d(caps) [B][C][D] (zero off the labelled capsule) */
+int cy_pick_capsule(const float* caps, const long long* y, float* out, int B, int C, int D, int backward, void* stream);
+
+/* ------------------------------------------------------------------ optimizer
+ * torch.optim.Adam step (main.py:72,280) for a list of tensors in ONE launch.
+ * table: device array of n_tensors records {param, grad, exp_avg, exp_avg_sq, numel} (5 x 8 bytes);
+ * blockmap: device array of n_blocks int2 {tensor index, chunk index}. */
+int cy_adam_multi(const void* table, const void* blockmap, int n_blocks, int chunk,
+                  float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
+                  void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

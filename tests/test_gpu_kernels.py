@@ -1,0 +1,289 @@
+"""Parity of every HIP kernel (through the C-ABI) against the CPU oracle / torch fp64 on seeded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import load_golden, make_params, routing_case, synth_gtsdb_labels, wave
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def close(a, b, rtol, atol_rel=0.0, atol=0.0):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, dtype=np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol + atol_rel * (np.abs(b).max() if b.size else 0.0))
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).float()
+
+
+# ------------------------------------------------------------------------------------------------ convolution
+CONV_CASES = [
+    # B, Cin, H, Cout, k, s, p, nchw
+    (2, 128, 12, 256, 3, 1, 1, False),     # conv_2 shape class (vec loader, 2 N tiles)
+    (2, 256, 16, 64, 4, 2, 1, False),      # conv_3 class (k4 s2, BN=64)
+    (3, 64, 10, 128, 4, 2, 1, False),      # conv_4 class
+    (2, 3, 20, 128, 3, 1, 1, True),        # conv_1: NCHW input, scalar loader, K=27
+    (2, 3, 17, 256, 9, 1, 0, True),        # CapsuleNet conv1 (K=243), odd size
+    (2, 256, 12, 128, 8, 2, 0, False),     # fused primary capsules conv (64 taps)
+    (2, 1024, 4, 10, 1, 1, 0, False),      # DarkNet conv_19 (N=10 padded)
+    (3, 16, 8, 4, 3, 1, 1, False),         # decoder conv (tiny channels)
+    (5, 32, 9, 64, 3, 1, 1, False),        # M not a multiple of the tile, Cin=32
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(case):
+    from capsyolo_amd import ops
+    B, Cin, H, Cout, k, s, p, nchw = case
+    x = rnd((B, Cin, H, H), 1)
+    w = rnd((Cout, Cin, k, k), 2, (1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd((Cout,), 3, 0.1)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    zr = F.conv2d(xd, wd, b.double(), stride=s, padding=p)
+    gz = rnd(tuple(zr.shape), 4)
+    zr.backward(gz.double())
+    xg = x.to(dev()) if nchw else x.permute(0, 2, 3, 1).contiguous().to(dev())
+    z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), k, s, p, nchw)
+    close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    dW = ops.conv_wgrad(xg, gzd, k, s, p, nchw)
+    close(dW, wd.grad, 5e-5, 5e-5)
+    if not nchw:
+        dx = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), k, s, p)
+        close(dx.permute(0, 3, 1, 2), xd.grad, 5e-5, 5e-5)
+
+
+def test_conv_relu_epilogue_and_stats():
+    from capsyolo_amd import ops
+    x = rnd((2, 64, 9, 9), 5)
+    w = rnd((128, 64, 3, 3), 6, 0.05)
+    b = rnd((128,), 7, 0.1)
+    zr = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    stats = torch.zeros((128, 2), dtype=torch.float64, device=dev())
+    z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1, False, stats, False)
+    close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
+    close(stats[:, 0], zr.sum(dim=(0, 2, 3)), 1e-5, 1e-5)
+    close(stats[:, 1], (zr ** 2).sum(dim=(0, 2, 3)), 1e-5, 1e-5)
+    z2 = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1, False, None, True)
+    close(z2.permute(0, 3, 1, 2), zr.clamp(min=0), 2e-5, 2e-5)
+
+
+@pytest.mark.parametrize('train', [True, False])
+def test_conv_bn_lrelu_block(train):
+    """Conv -> BatchNorm2d -> LeakyReLU(0.1) block vs torch modules (batch stats, running stats, all grads)."""
+    from capsyolo_amd import models
+    torch.manual_seed(3)
+    conv = torch.nn.Conv2d(32, 64, 4, 2, 1).double()
+    bn = torch.nn.BatchNorm2d(64).double()
+    bn.weight.data = 1 + 0.2 * torch.randn(64).double()
+    bn.bias.data = 0.1 * torch.randn(64).double()
+    bn.running_mean.data = 0.1 * torch.randn(64).double()
+    bn.running_var.data = 1 + 0.2 * torch.rand(64).double()
+    ref = torch.nn.Sequential(conv, bn, torch.nn.LeakyReLU(0.1)).train(train)
+    seq = models.FusedBackbone()
+    seq.add_module('conv_1', models.HipConv2d(32, 64, 4, 2, 1))
+    seq.add_module('bn_1', models.HipBatchNorm2d(64))
+    seq.add_module('relu_1', models.HipLeakyReLU(0.1))
+    seq.conv_1.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
+    seq.bn_1.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    seq.to(dev()).train(train)
+    x = rnd((3, 32, 10, 10), 8)
+    xr = x.double().requires_grad_(True)
+    yr = ref(xr)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    yh = seq(xh, nchw_in=False)
+    close(yh.permute(0, 3, 1, 2), yr, 1e-4, 1e-5)
+    close(seq.bn_1.running_mean, bn.running_mean, 1e-4, 1e-6)
+    close(seq.bn_1.running_var, bn.running_var, 1e-4, 1e-6)
+    if train:
+        g = rnd(tuple(yr.shape), 9)
+        yr.backward(g.double())
+        yh.backward(g.permute(0, 2, 3, 1).contiguous().to(dev()))
+        close(xh.grad.permute(0, 3, 1, 2), xr.grad, 1e-3, 1e-4)
+        close(seq.conv_1.weight.grad, conv.weight.grad, 1e-3, 1e-4)
+        close(seq.bn_1.weight.grad, bn.weight.grad, 1e-3, 1e-4)
+        close(seq.bn_1.bias.grad, bn.bias.grad, 1e-3, 1e-4)
+        assert float(seq.conv_1.bias.grad.abs().max()) == 0.0       # analytically zero in front of BN
+
+
+# ------------------------------------------------------------------------------------------------ routing
+@pytest.mark.parametrize('ci', [0, 1, 2, 3])
+@pytest.mark.parametrize('n_iter', [1, 3, 5])
+def test_routing_golden(ci, n_iter):
+    """HIP routing vs the reference's own outputs/gradients (tests/golden/routing.npz)."""
+    from capsyolo_amd import ops
+    from helpers import grad_digest
+    g = load_golden('routing')
+    R, N, C, Din, Dout = (int(v) for v in g['c%d_shape' % ci])
+    u, W, G = routing_case(ci, R, N, C, Din, Dout)
+    ut = T(u).to(dev()).requires_grad_(True)
+    Wt = T(W).to(dev()).requires_grad_(True)
+    v = ops.routing(ut, Wt, n_iter)
+    (v * T(G).to(dev())).sum().backward()
+    key = 'c%d_r%d_' % (ci, n_iter)
+    close(v, g[key + 'v'], 1e-4, 1e-5)
+    close(ut.grad, g[key + 'du'], 1e-3, 1e-4)
+    dig = grad_digest(Wt.grad.cpu())
+    close(dig, g[key + 'dW_digest'], 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(37, 70, 43, 8, 16, 3), (9, 33, 7, 8, 21, 2), (130, 512, 1, 8, 5, 3),
+                                   (5, 64, 64, 8, 16, 3), (3, 20, 3, 8, 5, 4)])
+def test_routing_vs_oracle(shape):
+    from capsyolo_amd import ops
+    from oracle.models import dynamic_routing
+    R, N, C, Din, Dout, n_iter = shape
+    u, W, G = rnd((R, N, Din), 11, 0.8), rnd((1, N, C, Din, Dout), 12, 0.15), rnd((R, C, Dout), 13)
+    ur, Wr = u.double().requires_grad_(True), W.double().requires_grad_(True)
+    vr = dynamic_routing(ur, Wr, n_iter)
+    (vr * G.double()).sum().backward()
+    ut, Wt = u.to(dev()).requires_grad_(True), W.to(dev()).requires_grad_(True)
+    v = ops.routing(ut, Wt, n_iter)
+    (v * G.to(dev())).sum().backward()
+    close(v, vr, 1e-4, 1e-5)
+    close(ut.grad, ur.grad, 1e-3, 1e-4)
+    close(Wt.grad, Wr.grad, 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize('C,Dout,n_iter', [(1, 5, 3), (3, 21, 3)])
+def test_routing_cell_gather(C, Dout, n_iter):
+    """Gather fused into the routing loads == oracle cell_gather + routing (DarkCapsuleNet / DarkCapsuleNet3 heads)."""
+    from capsyolo_amd import ops
+    from oracle.models import cell_gather, dynamic_routing
+    g, B = 3, 5
+    feat = rnd((B, 256, 4 * g, 4 * g), 21, 0.7)
+    W = rnd((1, 512, C, 8, Dout), 22, 0.1)
+    fr, Wr = feat.double().requires_grad_(True), W.double().requires_grad_(True)
+    vr = dynamic_routing(cell_gather(fr, g), Wr, n_iter)                   # [g*g*B, C, Dout]
+    vr = vr.reshape(g, g, B, C, Dout).permute(2, 0, 1, 3, 4)
+    G = rnd(tuple(vr.shape), 23)
+    (vr * G.double()).sum().backward()
+    fh = feat.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    Wh = W.to(dev()).requires_grad_(True)
+    v = ops.routing(fh, Wh, n_iter, g, B)
+    (v * G.to(dev())).sum().backward()
+    close(v, vr, 1e-4, 1e-5)
+    close(fh.grad.permute(0, 3, 1, 2), fr.grad, 1e-3, 1e-4)
+    close(Wh.grad, Wr.grad, 1e-3, 1e-4)
+
+
+def test_routing_singleton_is_iteration_independent():
+    from capsyolo_amd import ops
+    u, W = rnd((40, 512, 8), 31).to(dev()), rnd((1, 512, 1, 8, 5), 32, 0.1).to(dev())
+    outs = [ops.routing(u, W, r) for r in (1, 3, 5)]
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+
+
+def test_squash_and_length():
+    from capsyolo_amd import ops
+    from oracle.models import squash
+    g = load_golden('squash')
+    x = T(g['v']).to(dev()).requires_grad_(True)
+    y = ops.squash(x)
+    close(y, g['out'], 2e-5, 1e-6)
+    xr = T(g['v']).double().requires_grad_(True)
+    G = rnd(tuple(xr.shape), 41)
+    (squash(xr) * G.double()).sum().backward()
+    (y * G.to(dev())).sum().backward()
+    close(x.grad, xr.grad, 1e-4, 1e-5)
+    x2 = T(g['v']).to(dev()).requires_grad_(True)
+    x2r = T(g['v']).double().requires_grad_(True)
+    G2 = rnd(tuple(xr.shape[:-1]), 42)
+    (ops.length(x2) * G2.to(dev())).sum().backward()
+    (((x2r ** 2).sum(-1) ** 0.5) * G2.double()).sum().backward()
+    close(x2.grad, x2r.grad, 1e-4, 1e-5)
+    assert torch.isnan(ops.squash(torch.zeros(1, 4, device=dev()))).all()
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def test_losses_golden():
+    from capsyolo_amd import loss_fns
+    g = load_golden('losses')
+    p = make_params(recon=False, device='cuda')
+    ct = T(g['dc_caps']).to(dev()).requires_grad_(True)
+    l = loss_fns.darkcapsule_loss(ct, T(g['dc_y']).to(dev()), p)
+    (l * 1.0).backward()
+    close(l, g['dc_loss'], 2e-5)
+    close(ct.grad, g['dc_dcaps'], 1e-4, 1e-5)
+    xim = T(wave((5, 3, 32, 32), 0.1, amp=0.9, freq=0.211)).to(dev())
+    for recon in (False, True):
+        pc = make_params(recon=recon, device='cuda')
+        st = T(g['cap_scores']).to(dev()).requires_grad_(True)
+        rt = T(wave((5, 3, 32, 32), 2.1, amp=0.9, freq=0.173)).to(dev()).requires_grad_(True)
+        l = loss_fns.capsule_loss(st, T(g['cap_y']).to(dev()), pc, xim, rt)
+        (l * 2.0).backward()                                         # upstream gradient != 1
+        tag = 'cap_recon%d_' % int(recon)
+        close(l, g[tag + 'loss'], 2e-5)
+        close(st.grad, 2.0 * g[tag + 'dscores'], 1e-4, 1e-5)
+    for tag in ('dk_d', 'dk_r'):
+        nb, C, inp, gd = (int(v) for v in g[tag + '_cfg'])
+        pd = make_params(n_boxes=nb, n_classes=C, darknet_input=inp, n_grid=gd, device='cuda')
+        pt = T(g[tag + '_pred']).float().to(dev()).requires_grad_(True)
+        l = loss_fns.dark_loss(pt, T(g[tag + '_y']).to(dev()), pd)
+        l.backward()
+        close(l, g[tag + '_loss'], 5e-5)
+        close(pd.avg_iou, g[tag + '_avg_iou'], 5e-5)
+        close(pt.grad, g[tag + '_dpred'], 2e-4, 1e-5)
+
+
+def test_adam_matches_torch():
+    from capsyolo_amd import optim
+    torch.manual_seed(0)
+    shapes = [(1000,), (33, 7), (5, 3, 3, 3), (70000,)]
+    ps_ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ps_hip = [torch.nn.Parameter(p.detach().clone().to(dev())) for p in ps_ref]
+    o_ref, o_hip = torch.optim.Adam(ps_ref, lr=1e-2), optim.Adam(ps_hip, lr=1e-2)
+    for step in range(5):
+        for pr, ph in zip(ps_ref, ps_hip):
+            gr = torch.randn(pr.shape, generator=torch.Generator().manual_seed(step * 10 + pr.numel() % 7))
+            pr.grad, ph.grad = gr.clone(), gr.clone().to(dev())
+        o_ref.step()
+        o_hip.step()
+    for pr, ph in zip(ps_ref, ps_hip):
+        close(ph, pr, 1e-5, 1e-6)
+
+
+def test_misc_ops():
+    from capsyolo_amd import ops
+    x = rnd((2, 6, 8, 8), 51)
+    xh = x.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    G = rnd((2, 6, 4, 4), 52)
+    (F.max_pool2d(xr, 2) * G.double()).sum().backward()
+    y = ops.maxpool2(xh)
+    (y * G.permute(0, 2, 3, 1).contiguous().to(dev())).sum().backward()
+    close(y.permute(0, 3, 1, 2), F.max_pool2d(x, 2), 0, 0)
+    close(xh.grad.permute(0, 3, 1, 2), xr.grad, 1e-6)
+    # upsample
+    xh2 = x.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    xr2 = x.double().requires_grad_(True)
+    G2 = rnd((2, 6, 16, 16), 53)
+    (F.interpolate(xr2, scale_factor=2, mode='nearest') * G2.double()).sum().backward()
+    y2 = ops.upsample_nearest(xh2, 2)
+    (y2 * G2.permute(0, 2, 3, 1).contiguous().to(dev())).sum().backward()
+    close(y2.permute(0, 3, 1, 2), F.interpolate(x, scale_factor=2, mode='nearest'), 0, 0)
+    close(xh2.grad.permute(0, 3, 1, 2), xr2.grad, 1e-5, 1e-6)
+    # layout permutes round trip
+    close(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x.to(dev()))), x, 0, 0)
+    close(ops.nchw_to_nhwc(x.to(dev())), x.permute(0, 2, 3, 1), 0, 0)
+    # yolo head
+    h = rnd((3, 4, 4, 13), 54)
+    hr = h.double().requires_grad_(True)
+    ref = torch.cat((torch.sigmoid(hr[..., :10]), F.softmax(hr[..., 10:], dim=-1)), dim=-1)
+    G3 = rnd((3, 4, 4, 13), 55)
+    (ref * G3.double()).sum().backward()
+    hh = h.to(dev()).requires_grad_(True)
+    yh = ops.yolo_head(hh, 10, 3)
+    (yh * G3.to(dev())).sum().backward()
+    close(yh, ref, 1e-5, 1e-6)
+    close(hh.grad, hr.grad, 1e-4, 1e-5)
