@@ -37,6 +37,9 @@ CONV_CASES = [
     (2, 1024, 4, 10, 1, 1, 0, False),      # DarkNet conv_19 (N=10 padded)
     (3, 16, 8, 4, 3, 1, 1, False),         # decoder conv (tiny channels)
     (5, 32, 9, 64, 3, 1, 1, False),        # M not a multiple of the tile, Cin=32
+    (4, 128, 16, 256, 4, 2, 1, False),     # conv_5 at H=64 (as inside the DarkCapsuleNet golden model)
+    (4, 16, 32, 3, 3, 1, 1, False),        # decoder's last conv (Cout=3: dgrad runs the scalar loader with Cin=3)
+    (4, 64, 32, 128, 4, 2, 1, False),      # conv_4 at H=64
 ]
 
 
@@ -78,26 +81,27 @@ def test_conv_relu_epilogue_and_stats():
     close(z2.permute(0, 3, 1, 2), zr.clamp(min=0), 2e-5, 2e-5)
 
 
-@pytest.mark.parametrize('train', [True, False])
-def test_conv_bn_lrelu_block(train):
+@pytest.mark.parametrize('train,cin,cout,hw,B', [(True, 32, 64, 10, 3), (False, 32, 64, 10, 3), (True, 64, 128, 32, 4),
+                                                 (True, 32, 256, 12, 2), (True, 32, 1024, 6, 2), (True, 32, 32, 16, 5)])
+def test_conv_bn_lrelu_block(train, cin, cout, hw, B):
     """Conv -> BatchNorm2d -> LeakyReLU(0.1) block vs torch modules (batch stats, running stats, all grads)."""
     from capsyolo_amd import models
     torch.manual_seed(3)
-    conv = torch.nn.Conv2d(32, 64, 4, 2, 1).double()
-    bn = torch.nn.BatchNorm2d(64).double()
-    bn.weight.data = 1 + 0.2 * torch.randn(64).double()
-    bn.bias.data = 0.1 * torch.randn(64).double()
-    bn.running_mean.data = 0.1 * torch.randn(64).double()
-    bn.running_var.data = 1 + 0.2 * torch.rand(64).double()
+    conv = torch.nn.Conv2d(cin, cout, 4, 2, 1).double()
+    bn = torch.nn.BatchNorm2d(cout).double()
+    bn.weight.data = 1 + 0.2 * torch.randn(cout).double()
+    bn.bias.data = 0.1 * torch.randn(cout).double()
+    bn.running_mean.data = 0.1 * torch.randn(cout).double()
+    bn.running_var.data = 1 + 0.2 * torch.rand(cout).double()
     ref = torch.nn.Sequential(conv, bn, torch.nn.LeakyReLU(0.1)).train(train)
     seq = models.FusedBackbone()
-    seq.add_module('conv_1', models.HipConv2d(32, 64, 4, 2, 1))
-    seq.add_module('bn_1', models.HipBatchNorm2d(64))
+    seq.add_module('conv_1', models.HipConv2d(cin, cout, 4, 2, 1))
+    seq.add_module('bn_1', models.HipBatchNorm2d(cout))
     seq.add_module('relu_1', models.HipLeakyReLU(0.1))
     seq.conv_1.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
     seq.bn_1.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
     seq.to(dev()).train(train)
-    x = rnd((3, 32, 10, 10), 8)
+    x = rnd((B, cin, hw, hw), 8)
     xr = x.double().requires_grad_(True)
     yr = ref(xr)
     xh = x.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
