@@ -59,7 +59,7 @@ class FusedBackbone(nn.Sequential):
     forward walks the children and fuses each conv -> bn -> relu triple into one conv block."""
 
     def forward(self, x, nchw_in=True):
-        mods = list(self.children())
+        names, mods = zip(*self.named_children())
         i = 0
         while i < len(mods):
             m = mods[i]
@@ -67,7 +67,8 @@ class FusedBackbone(nn.Sequential):
                 bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], HipBatchNorm2d) else None
                 j = i + (2 if bn is not None else 1)
                 act = mods[j] if j < len(mods) and isinstance(mods[j], HipLeakyReLU) else None
-                cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, act.slope if act is not None else None)
+                cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, act.slope if act is not None else None,
+                                       names[i])
                 x = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
                                    bn.bias if bn is not None else None, cfg)
                 nchw_in = False

@@ -16,6 +16,44 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer(object):
+    """HIP-event brackets around selected launches on the stream they are launched on (bench.py's live
+    per-kernel durations).  Disabled by default: then ``range`` costs one attribute test."""
+
+    def __init__(self):
+        self.enabled = False
+        self.events = {}
+
+    class _Range(object):
+        def __init__(self, timer, name):
+            self.timer, self.name = timer, name
+
+        def __enter__(self):
+            if self.timer.enabled:
+                self.start = torch.cuda.Event(enable_timing=True)
+                self.start.record(torch.cuda.current_stream())
+
+        def __exit__(self, *exc):
+            if self.timer.enabled:
+                end = torch.cuda.Event(enable_timing=True)
+                end.record(torch.cuda.current_stream())
+                self.timer.events.setdefault(self.name, []).append((self.start, end))
+            return False
+
+    def range(self, name):
+        return KernelTimer._Range(self, name)
+
+    def reset(self):
+        self.events = {}
+
+    def summary(self):
+        """name -> (launches, mean milliseconds); call after a device synchronize."""
+        return dict((k, (len(v), sum(a.elapsed_time(b) for a, b in v) / len(v))) for k, v in self.events.items())
+
+
+timer = KernelTimer()
+
+
 def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
@@ -40,7 +78,7 @@ def _x_geometry(x, nchw):
     return B, Hi, Wi, Cin, (Hi * Wi * Cin, Wi * Cin, Cin, 1)
 
 
-def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False):
+def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv'):
     """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     Cout = weight.shape[0]
@@ -55,11 +93,12 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
                  xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                  TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1,
                  Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=1 if relu else 0)
-    call('cy_conv_gemm', C.byref(a), st)
+    with timer.range('conv_gemm_fwd/' + tag):
+        call('cy_conv_gemm', C.byref(a), st)
     return z
 
 
-def conv_dgrad(dz, weight, in_shape, k, stride, pad):
+def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
     """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride."""
     B, Hi, Wi, Cin = in_shape
     _, Ho, Wo, Cout = dz.shape
@@ -85,13 +124,14 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad):
                          Ho=Hv, Wo=Wv, N=Cin, TH=TH, TW=TW, in_stride=1,
                          dy0=(py + pad - kh0) // stride, dx0=(px + pad - kw0) // stride, dstep=-1,
                          Hy=Hi, Wy=Wi, out_stride=stride, out_oy=py, out_ox=px, act=0)
-            call('cy_conv_gemm', C.byref(a), st)
+            with timer.range('conv_gemm_dgrad/' + tag):
+                call('cy_conv_gemm', C.byref(a), st)
     if not covered:
         raise _lib.HipExtensionError('conv_dgrad: kernel %d / stride %d leaves input pixels without taps' % (k, stride))
     return dx
 
 
-def conv_wgrad(x, dz, k, stride, pad, nchw=False):
+def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     _, Ho, Wo, Cout = dz.shape
     st = _stream()
@@ -101,15 +141,16 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False):
                   KH=k, KW=k, stride=stride, pad=pad)
     ws = _empty((query('cy_conv_wgrad_ws_floats', C.byref(a)),), dz)
     a.slabs = ws.data_ptr()
-    call('cy_conv_wgrad', C.byref(a), st)
+    with timer.range('conv_wgrad/' + tag):
+        call('cy_conv_wgrad', C.byref(a), st)
     return dW
 
 
 class ConvBlockCfg(object):
     """Static description of one conv (+BatchNorm) (+activation) block."""
 
-    def __init__(self, k, stride, pad, nchw_in=False, bn=None, slope=None):
-        self.k, self.stride, self.pad, self.nchw_in = k, stride, pad, nchw_in
+    def __init__(self, k, stride, pad, nchw_in=False, bn=None, slope=None, name='conv'):
+        self.k, self.stride, self.pad, self.nchw_in, self.name = k, stride, pad, nchw_in, name
         self.bn = bn            # module with running_mean / running_var / momentum / eps / training, or None
         self.slope = slope      # None: no activation; 0.0: ReLU; else LeakyReLU slope
 
@@ -127,7 +168,7 @@ class _ConvBlock(torch.autograd.Function):
         ctx.cfg, ctx.has_bias, ctx.bn_train = cfg, bias is not None, False
         if bn is None:
             relu = cfg.slope is not None and cfg.slope == 0.0
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, relu)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, relu, cfg.name)
             out = z
             if cfg.slope is not None and not relu:
                 out = torch.empty_like(z)
@@ -138,7 +179,7 @@ class _ConvBlock(torch.autograd.Function):
         mean, invstd = _empty((N,), x), _empty((N,), x)
         if bn.training:
             stats = torch.zeros((N, 2), dtype=torch.float64, device=x.device)
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name)
             P = z.numel() // N
             call('cy_bn_finalize', _ptr(stats), P, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
                  _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean),
@@ -146,7 +187,7 @@ class _ConvBlock(torch.autograd.Function):
             bn.num_batches_tracked += 1
             ctx.bn_train = True
         else:
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False, cfg.name)
             P = z.numel() // N
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                  float(bn.eps), _ptr(scale), _ptr(shift), N, st)
@@ -190,12 +231,12 @@ class _ConvBlock(torch.autograd.Function):
             if ctx.has_bias:
                 # a bias in front of BatchNorm has an analytically zero gradient: sum(dz) == 0
                 dbias = torch.zeros((N,), dtype=torch.float32, device=z.device)
-        dW = conv_wgrad(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in)
+        dW = conv_wgrad(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, cfg.name)
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.nchw_in:
                 raise _lib.HipExtensionError('input gradient of an NCHW-input convolution is not implemented')
-            dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad)
+            dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, cfg.name)
         return dx, dW, dbias, dgamma, dbeta, None
 
 
@@ -219,7 +260,8 @@ class _Routing(torch.autograd.Function):
         s_hist = _empty((n_iter, R, Cc, Dout), u)
         a = RoutingFwd(u=u.data_ptr(), W=W.data_ptr(), v_out=v.data_ptr(), s_hist=s_hist.data_ptr(), R=R, N=N, C=Cc,
                        Din=Din, Dout=Dout, n_iter=n_iter, gather_g=gather_g, gather_B=gather_B)
-        call('cy_routing_fwd', C.byref(a), _stream())
+        with timer.range('routing_fwd'):
+            call('cy_routing_fwd', C.byref(a), _stream())
         ctx.save_for_backward(u, W, s_hist)
         ctx.dims = (R, N, Cc, Din, Dout, n_iter, gather_g, gather_B)
         return v
@@ -235,7 +277,8 @@ class _Routing(torch.autograd.Function):
                        gather_B=gB)
         ws = _empty((query('cy_routing_bwd_ws_floats', C.byref(a)),), u)
         a.ws = ws.data_ptr()
-        call('cy_routing_bwd', C.byref(a), _stream())
+        with timer.range('routing_bwd'):
+            call('cy_routing_bwd', C.byref(a), _stream())
         return du, dW, None, None, None
 
 
