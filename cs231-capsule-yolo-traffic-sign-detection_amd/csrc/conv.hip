@@ -57,9 +57,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
   if (t < BM) {
     long long p = m0 + t, off = -1;
     if (p < g.M) {
-      int b = (int)(p / HoWo);
-      int r = (int)(p - (long long)b * HoWo);
-      int oy = r / a.Wo, ox = r - oy * a.Wo;
+      const unsigned pp = (unsigned)p;
+      const unsigned b = pp / (unsigned)HoWo, r = pp - b * (unsigned)HoWo;
+      const int oy = (int)(r / (unsigned)a.Wo), ox = (int)(r - (unsigned)oy * (unsigned)a.Wo);
       off = (((long long)b * a.Hy + (oy * a.out_stride + a.out_oy)) * a.Wy + (ox * a.out_stride + a.out_ox)) * a.N;
     }
     rowoff[t] = off;
@@ -82,81 +82,51 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
   // scalar: thread owns pixel t&127, kq = 4*(t>>7) .. +3
   constexpr int NPIX = VEC ? 4 : 1;
   int iy0[NPIX], ix0[NPIX];
-  long long xb[NPIX];
+  long long xo[NPIX];                     // VEC: offset of tap (0,0), channel kq*4; scalar: batch base (floats)
 #pragma unroll
   for (int q = 0; q < NPIX; ++q) {
-    int pl = VEC ? ((t >> 3) + 32 * q) : (t & 127);
-    long long p = m0 + pl;
-    iy0[q] = -(1 << 28); ix0[q] = -(1 << 28); xb[q] = 0;
+    const int pl = VEC ? ((t >> 3) + 32 * q) : (t & 127);
+    const long long p = m0 + pl;
+    iy0[q] = -(1 << 28); ix0[q] = -(1 << 28); xo[q] = 0;
     if (p < g.M) {
-      int b = (int)(p / HoWo);
-      int r = (int)(p - (long long)b * HoWo);
-      int oy = r / a.Wo, ox = r - oy * a.Wo;
+      const unsigned pp = (unsigned)p;
+      const unsigned b = pp / (unsigned)HoWo, r = pp - b * (unsigned)HoWo;
+      const int oy = (int)(r / (unsigned)a.Wo), ox = (int)(r - (unsigned)oy * (unsigned)a.Wo);
       iy0[q] = oy * a.in_stride + (VEC ? a.dy0 : 0);
       ix0[q] = ox * a.in_stride + (VEC ? a.dx0 : 0);
-      xb[q] = (long long)b * a.xs_b;
+      xo[q] = (long long)b * a.xs_b +
+              (VEC ? ((long long)iy0[q] * a.xs_y + (long long)ix0[q] * a.xs_x + (t & 7) * 4) : 0ll);
     }
   }
-  const int kq_ld = t & 7;
-  float4 ra[4], rb[NBQ];
+  float4 ra0, ra1, ra2, ra3;
+  f32x4 rb[NBQ];
   int tap_a = 0, tap_b = 0, c0 = 0;       // position of the NEXT tile to load (VEC)
+  // B tile: float4 index f = t + 256q -> kq = f / BN, n = f % BN  (BN is a power of two)
+  const int b_kq0 = t / BN, b_n = t % BN;
+  const float* wsrc = a.Wp + ((long long)b_kq0 * g.Np + n0 + b_n) * 4;
+  constexpr int B_KQ_STEP = 256 / BN;     // kq advance per q
+  const long long w_tile = (long long)8 * g.Np * 4;
 
-  auto load_tile = [&](int kt) {
-    if (VEC) {
-      const int dy = tap_a * a.dstep, dx = tap_b * a.dstep;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int iy = iy0[q] + dy, ix = ix0[q] + dx;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-          v = *(const float4*)(a.X + xb[q] + (long long)iy * a.xs_y + (long long)ix * a.xs_x + c0 + kq_ld * 4);
-        ra[q] = v;
-      }
-      c0 += 32;
-      if (c0 >= a.Cin) { c0 = 0; if (++tap_b == a.TW) { tap_b = 0; ++tap_a; } }
-    } else {
-      const int half = t >> 7;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int ent = ktab[kt * 32 + (half * 4 + j) * 4 + e];
-          int c = ent & 0xffff;
-          int iy = iy0[0] + (int)(signed char)((ent >> 16) & 0xff);
-          int ix = ix0[0] + (int)(signed char)((ent >> 24) & 0xff);
-          float x = 0.f;
-          if (ent != -1 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-            x = a.X[xb[0] + (long long)iy * a.xs_y + (long long)ix * a.xs_x + (long long)c * a.xs_c];
-          v[e] = x;
-        }
-        ra[j] = make_float4(v[0], v[1], v[2], v[3]);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < NBQ; ++q) {
-      int f = t + 256 * q;
-      int kq = f / BN, n = f % BN;
-      rb[q] = *(const float4*)(a.Wp + ((long long)(kt * 8 + kq) * g.Np + n0 + n) * 4);
-    }
-  };
-  auto store_tile = [&](int buf) {
-    float* Ab = As + buf * A_BUF;
-    float* Bb = Bs + buf * B_BUF;
-    if (VEC) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) *(float4*)(Ab + kq_ld * A_KQ + ((t >> 3) + 32 * q) * 4) = ra[q];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) *(float4*)(Ab + ((t >> 7) * 4 + j) * A_KQ + (t & 127) * 4) = ra[j];
-    }
-#pragma unroll
-    for (int q = 0; q < NBQ; ++q) {
-      int f = t + 256 * q;
-      int kq = f / BN, n = f % BN;
-      *(float4*)(Bb + kq * B_KQ + n * 4) = rb[q];
-    }
-  };
+#define CY_LOAD_A_VEC(R, Q)                                                                        \
+  {                                                                                                \
+    const int iy = iy0[Q] + dy, ix = ix0[Q] + dx;                                                  \
+    R = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
+    if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi) R = *(const float4*)(a.X + (xo[Q] + toff)); \
+  }
+#define CY_LOAD_A_SCALAR(R, J)                                                                     \
+  {                                                                                                \
+    float v_[4];                                                                                   \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                \
+      const int ent = ktab[ktn * 32 + ((t >> 7) * 4 + J) * 4 + e];                                 \
+      const int iy = iy0[0] + (int)(signed char)((ent >> 16) & 0xff);                              \
+      const int ix = ix0[0] + (int)(signed char)((ent >> 24) & 0xff);                              \
+      float x_ = 0.f;                                                                              \
+      if (ent != -1 && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)             \
+        x_ = a.X[xo[0] + (long long)iy * a.xs_y + (long long)ix * a.xs_x + (long long)(ent & 0xffff) * a.xs_c]; \
+      v_[e] = x_;                                                                                  \
+    }                                                                                              \
+    R = make_float4(v_[0], v_[1], v_[2], v_[3]);                                                   \
+  }
 
   f32x16 acc[2][NTW];
 #pragma unroll
@@ -167,36 +137,85 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   __syncthreads();                         // ktab / rowoff visible
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
 
-  for (int kt = 0; kt < g.KT; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < g.KT) load_tile(kt + 1);
-    const float* Ab = As + cur * A_BUF + (wave_m * 64 + li) * 4;
-    const float* Bb = Bs + cur * B_BUF + (wave_n * 32 * NTW + li) * 4;
+  // kt = -1 is the prologue (load + store tile 0, nothing to compute)
+  for (int kt = -1; kt < g.KT; ++kt) {
+    const int ktn = kt + 1;
+    const bool more = ktn < g.KT;
+    if (more) {
+      // B first: hipcc guards the B destination registers with a conservative vmcnt wait, which is free
+      // while nothing is in flight and would otherwise drain the A loads issued just before it
 #pragma unroll
-    for (int kg = 0; kg < 4; ++kg) {
-      const int kq = 2 * kg + lh;
-      float4 fa[2], fb[NTW];
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi) fa[mi] = *(const float4*)(Ab + kq * A_KQ + mi * 128);
-#pragma unroll
-      for (int ni = 0; ni < NTW; ++ni) fb[ni] = *(const float4*)(Bb + kq * B_KQ + ni * 128);
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NTW; ++ni) {
-          acc[mi][ni] = mfma32(fa[mi].x, fb[ni].x, acc[mi][ni]);
-          acc[mi][ni] = mfma32(fa[mi].y, fb[ni].y, acc[mi][ni]);
-          acc[mi][ni] = mfma32(fa[mi].z, fb[ni].z, acc[mi][ni]);
-          acc[mi][ni] = mfma32(fa[mi].w, fb[ni].w, acc[mi][ni]);
-        }
+      for (int q = 0; q < NBQ; ++q) rb[q] = *(const f32x4*)(wsrc + (long long)q * B_KQ_STEP * g.Np * 4);
+      wsrc += w_tile;
+      if (VEC) {
+        const int dy = tap_a * a.dstep, dx = tap_b * a.dstep;
+        const long long toff = (long long)dy * a.xs_y + (long long)dx * a.xs_x + c0;
+        CY_LOAD_A_VEC(ra0, 0) CY_LOAD_A_VEC(ra1, 1) CY_LOAD_A_VEC(ra2, 2) CY_LOAD_A_VEC(ra3, 3)
+        c0 += 32;
+        if (c0 >= a.Cin) { c0 = 0; if (++tap_b == a.TW) { tap_b = 0; ++tap_a; } }
+      } else {
+        CY_LOAD_A_SCALAR(ra0, 0) CY_LOAD_A_SCALAR(ra1, 1) CY_LOAD_A_SCALAR(ra2, 2) CY_LOAD_A_SCALAR(ra3, 3)
+      }
     }
-    if (kt + 1 < g.KT) store_tile(cur ^ 1);
+    if (kt >= 0) {
+      const int cur = kt & 1;
+      const float* Ab = As + cur * A_BUF + (wave_m * 64 + li) * 4;
+      const float* Bb = Bs + cur * B_BUF + (wave_n * 32 * NTW + li) * 4;
+      // fragment registers are double-buffered: group kg+1 is fetched from LDS before group kg's MFMAs issue
+      f32x4 fa[2][2], fb[2][NTW];
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi) fa[0][mi] = *(const f32x4*)(Ab + lh * A_KQ + mi * 128);
+#pragma unroll
+      for (int ni = 0; ni < NTW; ++ni) fb[0][ni] = *(const f32x4*)(Bb + lh * B_KQ + ni * 128);
+#pragma unroll
+      for (int kg = 0; kg < 4; ++kg) {
+        const int cb = kg & 1, nb = cb ^ 1;
+        if (kg < 3) {
+          const int kq = 2 * (kg + 1) + lh;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) fa[nb][mi] = *(const f32x4*)(Ab + kq * A_KQ + mi * 128);
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni) fb[nb][ni] = *(const f32x4*)(Bb + kq * B_KQ + ni * 128);
+        }
+        __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of this group's MFMAs
+        // LDS reads return in order: this group's fragments are ready once all but the 2+NTW reads just
+        // issued have landed (s_waitcnt lgkmcnt(N), vmcnt/expcnt untouched)
+        if (kg < 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((2 + NTW) << 8));
+        else __builtin_amdgcn_s_waitcnt(0xC07F);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NTW; ++ni) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[mi][ni] = mfma32(fa[cb][mi][e], fb[cb][ni][e], acc[mi][ni]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (more) {
+      float* Ab = As + (ktn & 1) * A_BUF;
+      float* Bb = Bs + (ktn & 1) * B_BUF;
+      if (VEC) {
+        float* dst = Ab + (t & 7) * A_KQ + (t >> 3) * 4;
+        *(float4*)(dst) = ra0;
+        *(float4*)(dst + 128) = ra1;
+        *(float4*)(dst + 256) = ra2;
+        *(float4*)(dst + 384) = ra3;
+      } else {
+        float* dst = Ab + (t >> 7) * 4 * A_KQ + (t & 127) * 4;
+        *(float4*)(dst) = ra0;
+        *(float4*)(dst + A_KQ) = ra1;
+        *(float4*)(dst + 2 * A_KQ) = ra2;
+        *(float4*)(dst + 3 * A_KQ) = ra3;
+      }
+#pragma unroll
+      for (int q = 0; q < NBQ; ++q) *(f32x4*)(Bb + (b_kq0 + q * B_KQ_STEP) * B_KQ + b_n * 4) = rb[q];
+    }
     __syncthreads();
   }
+#undef CY_LOAD_A_VEC
+#undef CY_LOAD_A_SCALAR
 
   // ---- epilogue: bias, activation, store, optional BatchNorm statistics
   float ssum[NTW], ssq[NTW];
@@ -269,17 +288,23 @@ __global__ void pack_weights_kernel(const float* __restrict__ W, float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Weight gradient: slab[split][k][n] = sum over the split's pixels of Xpatch[p][k] * dZ[p][n].
-// Both operands are k(reduction)-major in NHWC memory already: lane (i,h) of MFMA step s reads
-// X_lds[2s+h][i] and dZ_lds[2s+h][j] with ds_read_b32, conflict-free.
+// The reduction dimension is the pixel.  A stage is PT = 32 pixels = 8 groups of 4; both operands are staged
+// in LDS as [pixel group][e][u][4 pixels] (channel c = 4u + e), so that -- exactly as in the forward kernel --
+// lane (i,h) fetches 4 MFMA steps with ONE ds_read_b128: group 2kg+h, step t multiplies pixels 4(2kg)+t and
+// 4(2kg+1)+t.  The 4x4 (pixel x channel) transpose happens for free in registers: a thread loads the same 4
+// channels of 4 consecutive pixels and writes one float4 per channel.  MFMA row i of a 32-row sub-tile is
+// channel 4*(i%8) + i/8 of it; with an e-row stride of 8 (mod 16) slots both the ds_write_b128 (8 consecutive
+// lanes -> 8 consecutive slots) and the ds_read_b128 (16-lane groups) are bank-conflict free.
 constexpr int PT = 32;                     // pixels per pipeline stage
+__host__ __device__ constexpr int wg_row_stride(int U) { return U + ((8 - (U % 16) + 16) % 16); }
 
 template <int MT, int NT, int WM, int WN, bool VEC>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(cy_conv_wgrad_t a, int K, long long M, long long pix_per_split) {
   constexpr int BMK = 32 * MT * WM, BNN = 32 * NT * WN;
-  constexpr int LDA = BMK, LDB = BNN;
-  constexpr int A_BUF = PT * LDA, B_BUF = PT * LDB;
-  constexpr int NA = (PT * BMK / 4 + 255) / 256;   // float4 per thread (VEC) per stage
-  constexpr int NB = (PT * BNN / 4 + 255) / 256;
+  constexpr int UA = BMK / 4, UB = BNN / 4;
+  constexpr int RSA = wg_row_stride(UA), RSB = wg_row_stride(UB);     // slots (16 B) per e-row
+  constexpr int A_BUF = 8 * 4 * RSA * 4, B_BUF = 8 * 4 * RSB * 4;      // floats per stage buffer
+  constexpr int NIA = (8 * UA + 255) / 256, NIB = (8 * UB + 255) / 256; // items (pixel group x channel quad) per thread
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* As = smem;
   float* Zs = smem + 2 * A_BUF;
@@ -294,120 +319,121 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(cy_conv_wgrad_t a, i
   if (p_end > M) p_end = M;
   const int HoWo = a.Ho * a.Wo;
 
-  // A loader geometry
-  constexpr int UA = BMK / 4;              // float4 units per pixel row
-  int a_dy[NA], a_dx[NA], a_c[NA], a_row[NA], a_u[NA];
-  bool a_ok[NA];
-  if (VEC) {
+  // ---- A items of this thread: (pixel group pgA, channel quad uA); tap / channel are fixed per thread
+  int a_dy[NIA], a_dx[NIA], a_c[NIA], a_pg[NIA], a_u[NIA];
+  bool a_ok[NIA];
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      int f = t + 256 * j;
-      a_row[j] = f / UA; a_u[j] = f % UA;
-      int kk = kk0 + a_u[j] * 4;
-      a_ok[j] = (f < PT * UA) && (kk < K);
-      int tap = kk / a.Cin, c = kk - tap * a.Cin;
-      int kh = tap / a.KW, kw = tap - kh * a.KW;
+  for (int j = 0; j < NIA; ++j) {
+    const int it = t + 256 * j;
+    a_pg[j] = it / UA; a_u[j] = it % UA;
+    const int kk = kk0 + a_u[j] * 4;
+    a_ok[j] = (it < 8 * UA) && (kk < K);
+    a_dy[j] = a_dx[j] = a_c[j] = 0;
+    if (VEC) {
+      const int tap = kk / a.Cin, c = kk - tap * a.Cin;
+      const int kh = tap / a.KW, kw = tap - kh * a.KW;
       a_dy[j] = kh - a.pad; a_dx[j] = kw - a.pad; a_c[j] = c;
     }
-  } else {
+  }
+  if (!VEC) {
     for (int k = t; k < BMK; k += 256) {
-      int kk = kk0 + k, ent = -1;
+      const int kk = kk0 + k;
+      int ent = -1;
       if (kk < K) {
-        int tap = kk / a.Cin, c = kk - tap * a.Cin;
-        int kh = tap / a.KW, kw = tap - kh * a.KW;
+        const int tap = kk / a.Cin, c = kk - tap * a.Cin;
+        const int kh = tap / a.KW, kw = tap - kh * a.KW;
         ent = (c & 0xffff) | (((kh - a.pad) & 0xff) << 16) | (((kw - a.pad) & 0xff) << 24);
       }
       ktab[k] = ent;
     }
     __syncthreads();
   }
-  constexpr int UB = BNN / 4;
   const bool zvec = ((a.N & 3) == 0) && (((uintptr_t)a.dZ & 15) == 0);
-  float4 ra[VEC ? NA : (PT * BMK / 256 / 4 > 0 ? PT * BMK / 256 / 4 : 1)];
-  float4 rb[NB];
 
-  auto decompose = [&](long long p, int& b, int& oy, int& ox) {
-    b = (int)(p / HoWo);
-    int r = (int)(p - (long long)b * HoWo);
-    oy = r / a.Wo; ox = r - oy * a.Wo;
-  };
+  // pixel cursor (batch index, in-image linear index) of pixel p_begin + 4*a_pg[0]; advanced by PT per stage.
+  // Items j > 0 of a thread sit 256/UA groups further (same u).
+  unsigned cur_b, cur_r;
+  {
+    const long long p0 = p_begin + 4 * a_pg[0];
+    cur_b = (unsigned)(p0 / HoWo);
+    cur_r = (unsigned)(p0 - (long long)cur_b * HoWo);
+  }
+  f32x4 ra[NIA][4], rb[NIB][4];            // [item][pixel] = 4 channels
+
   auto load_stage = [&](long long ps) {
-    if (VEC) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        long long p = ps + a_row[j];
-        if (a_ok[j] && p < p_end) {
-          int b, oy, ox; decompose(p, b, oy, ox);
-          int iy = oy * a.stride + a_dy[j], ix = ox * a.stride + a_dx[j];
-          if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-            v = *(const float4*)(a.X + (long long)b * a.xs_b + (long long)iy * a.xs_y + (long long)ix * a.xs_x + a_c[j]);
-        }
-        ra[j] = v;
-      }
-    } else {
-      // scalar: thread -> pixel row (t & 31), k group (t >> 5) of BMK/8 elements (BMK = 32 -> 4 floats)
-      constexpr int EPT = PT * BMK / 256;  // elements per thread (multiple of 4)
-      const int row = t % PT, kbase = (t / PT) * EPT;
-      long long p = ps + row;
-      int b = 0, oy = 0, ox = 0;
-      const bool pv = p < p_end;
-      if (pv) decompose(p, b, oy, ox);
+    for (int j = 0; j < NIA; ++j) {
+      unsigned b = cur_b, r = cur_r + 4 * (a_pg[j] - a_pg[0]);
+      while (r >= (unsigned)HoWo) { r -= (unsigned)HoWo; ++b; }
+      int oy = (int)(r / (unsigned)a.Wo), ox = (int)(r - (unsigned)oy * (unsigned)a.Wo);
+      const long long pbase = ps + 4 * a_pg[j];
 #pragma unroll
-      for (int j = 0; j < EPT / 4; ++j) {
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int ent = ktab[kbase + j * 4 + e];
-          float x = 0.f;
-          if (pv && ent != -1) {
-            int iy = oy * a.stride + (int)(signed char)((ent >> 16) & 0xff);
-            int ix = ox * a.stride + (int)(signed char)((ent >> 24) & 0xff);
+      for (int q = 0; q < 4; ++q) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (a_ok[j] && pbase + q < p_end) {
+          if (VEC) {
+            const int iy = oy * a.stride + a_dy[j], ix = ox * a.stride + a_dx[j];
             if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-              x = a.X[(long long)b * a.xs_b + (long long)iy * a.xs_y + (long long)ix * a.xs_x + (long long)(ent & 0xffff) * a.xs_c];
+              v = *(const f32x4*)(a.X + ((long long)b * a.xs_b + (long long)iy * a.xs_y + (long long)ix * a.xs_x + a_c[j]));
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int ent = ktab[a_u[j] * 4 + e];
+              if (ent != -1) {
+                const int iy = oy * a.stride + (int)(signed char)((ent >> 16) & 0xff);
+                const int ix = ox * a.stride + (int)(signed char)((ent >> 24) & 0xff);
+                if ((unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
+                  v[e] = a.X[(long long)b * a.xs_b + (long long)iy * a.xs_y + (long long)ix * a.xs_x + (long long)(ent & 0xffff) * a.xs_c];
+              }
+            }
           }
-          v[e] = x;
         }
-        ra[j] = make_float4(v[0], v[1], v[2], v[3]);
+        ra[j][q] = v;
+        if (++ox == a.Wo) { ox = 0; if (++oy == a.Ho) { oy = 0; ++b; } }
       }
     }
+    cur_r += PT;
+    while (cur_r >= (unsigned)HoWo) { cur_r -= (unsigned)HoWo; ++cur_b; }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      int f = t + 256 * j;
-      int row = f / UB, u = f % UB;
-      long long p = ps + row;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (f < PT * UB && p < p_end) {
-        const float* src = a.dZ + p * a.N + n0 + u * 4;
-        if (zvec && n0 + u * 4 + 3 < a.N) v = *(const float4*)src;
-        else {
-          float tmp[4] = {0.f, 0.f, 0.f, 0.f};
-          for (int e = 0; e < 4; ++e) if (n0 + u * 4 + e < a.N) tmp[e] = src[e];
-          v = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]);
+    for (int j = 0; j < NIB; ++j) {
+      const int it = t + 256 * j;
+      const int pg = it / UB, u = it % UB;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const long long p = ps + 4 * pg + q;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (it < 8 * UB && p < p_end) {
+          const float* src = a.dZ + (p * a.N + n0 + u * 4);
+          if (zvec && n0 + u * 4 + 3 < a.N) v = *(const f32x4*)src;
+          else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (n0 + u * 4 + e < a.N) ? src[e] : 0.f;
+          }
         }
+        rb[j][q] = v;
       }
-      rb[j] = v;
     }
   };
   auto store_stage = [&](int buf) {
     float* Ab = As + buf * A_BUF;
     float* Zb = Zs + buf * B_BUF;
-    if (VEC) {
 #pragma unroll
-      for (int j = 0; j < NA; ++j) {
-        int f = t + 256 * j;
-        if (f < PT * UA) *(float4*)(Ab + a_row[j] * LDA + a_u[j] * 4) = ra[j];
+    for (int j = 0; j < NIA; ++j) {
+      if (t + 256 * j < 8 * UA) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *(f32x4*)(Ab + ((a_pg[j] * 4 + e) * RSA + a_u[j]) * 4) = f32x4{ra[j][0][e], ra[j][1][e], ra[j][2][e], ra[j][3][e]};
       }
-    } else {
-      constexpr int EPT = PT * BMK / 256;
-      const int row = t % PT, kbase = (t / PT) * EPT;
-#pragma unroll
-      for (int j = 0; j < EPT / 4; ++j) *(float4*)(Ab + row * LDA + kbase + j * 4) = ra[j];
     }
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-      int f = t + 256 * j;
-      if (f < PT * UB) *(float4*)(Zb + (f / UB) * LDB + (f % UB) * 4) = rb[j];
+    for (int j = 0; j < NIB; ++j) {
+      const int it = t + 256 * j;
+      if (it < 8 * UB) {
+        const int pg = it / UB, u = it % UB;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          *(f32x4*)(Zb + ((pg * 4 + e) * RSB + u) * 4) = f32x4{rb[j][0][e], rb[j][1][e], rb[j][2][e], rb[j][3][e]};
+      }
     }
   };
 
@@ -425,22 +451,40 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(cy_conv_wgrad_t a, i
     store_stage(0);
   }
   __syncthreads();
+  // fragment of MFMA row/col `li` of sub-tile s, pixel group pg: slot (pg*4 + li/8)*RS + 8*s + li%8
+  const int fragA = ((li >> 3) * RSA + 8 * (wm * MT) + (li & 7)) * 4;
+  const int fragB = ((li >> 3) * RSB + 8 * (wn * NT) + (li & 7)) * 4;
   for (long long st = 0; st < nstages; ++st) {
     const int cur = (int)(st & 1);
     if (st + 1 < nstages) load_stage(p_begin + (st + 1) * PT);
-    const float* Ab = As + cur * A_BUF + wm * 32 * MT + li;
-    const float* Zb = Zs + cur * B_BUF + wn * 32 * NT + li;
+    const float* Ab = As + cur * A_BUF + fragA;
+    const float* Zb = Zs + cur * B_BUF + fragB;
+    f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
-    for (int s = 0; s < PT / 2; ++s) {
-      float fa[MT], fb[NT];
+    for (int mi = 0; mi < MT; ++mi) fa[0][mi] = *(const f32x4*)(Ab + (lh * 4 * RSA + 8 * mi) * 4);
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi) fa[mi] = Ab[(2 * s + lh) * LDA + mi * 32];
+    for (int ni = 0; ni < NT; ++ni) fb[0][ni] = *(const f32x4*)(Zb + (lh * 4 * RSB + 8 * ni) * 4);
 #pragma unroll
-      for (int ni = 0; ni < NT; ++ni) fb[ni] = Zb[(2 * s + lh) * LDB + ni * 32];
+    for (int kg = 0; kg < 4; ++kg) {
+      const int cb = kg & 1, nb = cb ^ 1;
+      if (kg < 3) {
+        const int pg = 2 * (kg + 1) + lh;
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) fa[nb][mi] = *(const f32x4*)(Ab + (pg * 4 * RSA + 8 * mi) * 4);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) fb[nb][ni] = *(const f32x4*)(Zb + (pg * 4 * RSB + 8 * ni) * 4);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (kg < 3) __builtin_amdgcn_s_waitcnt(0xC07F | ((MT + NT) << 8));
+      else __builtin_amdgcn_s_waitcnt(0xC07F);
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma32(fa[mi], fb[ni], acc[mi][ni]);
+        for (int ni = 0; ni < NT; ++ni) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[mi][ni] = mfma32(fa[cb][mi][e], fb[cb][ni][e], acc[mi][ni]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (st + 1 < nstages) store_stage(cur ^ 1);
     __syncthreads();
@@ -451,10 +495,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(cy_conv_wgrad_t a, i
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) {
-      const int n = n0 + wn * 32 * NT + ni * 32 + li;
+      const int n = n0 + (wn * NT + ni) * 32 + 4 * (li & 7) + (li >> 3);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int kk = kk0 + wm * 32 * MT + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int ri = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int kk = kk0 + (wm * MT + mi) * 32 + 4 * (ri & 7) + (ri >> 3);
         if (kk < K && n < a.N) slab[(long long)kk * a.N + n] = acc[mi][ni][r];
       }
     }
@@ -492,14 +537,25 @@ __global__ void channel_sum_kernel(const float* __restrict__ dZ, float* __restri
   if (wave == 0 && n < N) atomicAdd(out + n, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
+// Pixel splits of the weight-gradient reduction.  Blocks are long-running (thousands of MFMA stages) and only
+// 2 fit a CU (80 KiB of LDS each), so the grid is sized to fill whole rounds of the 512 resident slots: a grid
+// of 3.02 rounds costs 4.
 int pick_splits(int tiles, long long M) {
-  long long s = (1536 + tiles - 1) / tiles;
-  long long cap = M / 2048;
+  const long long capacity = 512;
+  long long cap = M / 1024;                 // keep >= 1024 pixels (32 stages) per split
   if (cap < 1) cap = 1;
-  if (s > cap) s = cap;
-  if (s < 1) s = 1;
-  if (s > 512) s = 512;
-  return (int)s;
+  long long best = 1;
+  double best_util = 0.0;
+  for (long long rounds = 1; rounds <= 4; ++rounds) {
+    long long sp = capacity * rounds / tiles;
+    if (sp < 1) sp = 1;
+    if (sp > cap) sp = cap;
+    const long long blocks = sp * tiles;
+    const double util = (double)blocks / (double)(capacity * ((blocks + capacity - 1) / capacity));
+    if (util > best_util + 0.02) { best_util = util; best = sp; }
+  }
+  if (best > 1024) best = 1024;
+  return (int)best;
 }
 
 struct WgradPlan { int variant, BMK, BNN, ktiles, ntiles, S; long long pix_per_split; bool vec; };
@@ -571,7 +627,7 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   const int BN = 64 * ntw;
   const long long mtiles = cy_ceil_div(g.M, BM);
   const long long nblocks = mtiles * (g.Np / BN);
-  CY_REQUIRE(nblocks < (1ll << 31), "cy_conv_gemm: grid too large");
+  CY_REQUIRE(nblocks < (1ll << 31) && g.M < (1ll << 31), "cy_conv_gemm: grid too large");
   size_t lds = (size_t)(2 * 8 * A_KQ + 2 * 8 * (BN * 4 + 4)) * 4 + BM * 8 + (vec ? 0 : (size_t)g.KT * 32 * 4);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nblocks), block(256);
@@ -606,7 +662,7 @@ extern "C" int cy_conv_wgrad(const cy_conv_wgrad_t* a, void* stream) {
   CY_REQUIRE(p.vec || a->Cin <= 65535, "cy_conv_wgrad: Cin too large for the scalar loader");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(p.ktiles, p.ntiles, p.S), block(256);
-  size_t lds = (size_t)(2 * PT * p.BMK + 2 * PT * p.BNN) * 4 + (p.vec ? 0 : p.BMK * 4);
+  size_t lds = (size_t)2 * 8 * 4 * 4 * (wg_row_stride(p.BMK / 4) + wg_row_stride(p.BNN / 4)) * 4 + (p.vec ? 0 : p.BMK * 4);
 #define CY_WGRAD_LAUNCH(...)                                                       \
   do {                                                                             \
     int rc__ = cy_allow_lds(conv_wgrad_kernel<__VA_ARGS__>, lds);                  \

@@ -1,0 +1,70 @@
+"""Run the hot kernels alone (for rocprofv3 --pmc passes and quick A/B timing).
+usage: python3 tools/run_kernels.py [conv2|routing|all] [B] [reps]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import capsyolo_amd
+from capsyolo_amd import ops
+
+what = sys.argv[1] if len(sys.argv) > 1 else 'all'
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+
+
+def timeit(name, fn, flops=None, nbytes=None):
+    fn(); torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record(); torch.cuda.synchronize()
+    ms = s.elapsed_time(e) / reps
+    extra = ''
+    if flops: extra += '  %.1f TFLOP/s' % (flops / ms / 1e9)
+    if nbytes: extra += '  %.1f GB/s' % (nbytes / ms / 1e6)
+    print('%-28s %9.3f ms%s' % (name, ms, extra), flush=True)
+
+
+if what in ('conv2', 'all'):
+    H = 416
+    x = torch.randn(B, H, H, 128, device=dev)
+    w = torch.randn(256, 128, 3, 3, device=dev) * 0.03
+    b = torch.zeros(256, device=dev)
+    dz = torch.randn(B, H, H, 256, device=dev)
+    fl = 2.0 * B * H * H * 256 * 1152
+    stats = torch.zeros(256, 2, dtype=torch.float64, device=dev)
+    timeit('conv2 fwd (+stats)', lambda: ops.conv_forward(x, w, b, 3, 1, 1, False, stats, False), fl)
+    timeit('conv2 dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, 128), 3, 1, 1), fl)
+    timeit('conv2 wgrad', lambda: ops.conv_wgrad(x, dz, 3, 1, 1), fl)
+    del x, dz
+if what in ('conv3', 'all'):
+    H = 416
+    x = torch.randn(B, H, H, 256, device=dev)
+    w = torch.randn(64, 256, 4, 4, device=dev) * 0.03
+    dz = torch.randn(B, H // 2, H // 2, 64, device=dev)
+    fl = 2.0 * B * (H // 2) ** 2 * 64 * 4096
+    timeit('conv3 fwd', lambda: ops.conv_forward(x, w, None, 4, 2, 1), fl)
+    timeit('conv3 dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, 256), 4, 2, 1), fl)
+    timeit('conv3 wgrad', lambda: ops.conv_wgrad(x, dz, 4, 2, 1), fl)
+    del x, dz
+if what in ('routing', 'all'):
+    g = 13
+    feat = torch.randn(B, 4 * g, 4 * g, 256, device=dev, requires_grad=True)
+    W = (0.1 * torch.randn(1, 512, 1, 8, 5, device=dev)).requires_grad_(True)
+    R = g * g * B
+    nb = 4.0 * (R * 4096 + 4096 * 5 + R * 5)
+    timeit('routing fwd C=1 (gather)', lambda: ops.routing(feat.detach(), W.detach(), 3, g, B), None, nb)
+    v = ops.routing(feat, W, 3, g, B)
+    gv = torch.randn_like(v)
+    timeit('routing fwd+bwd C=1', lambda: torch.autograd.grad(ops.routing(feat, W, 3, g, B), (feat, W), gv), None, None)
+    # general C (CapsuleNet head, B rows) and DarkCapsuleNet3-like head
+    u = torch.randn(B, 1296, 8, device=dev, requires_grad=True)
+    W2 = (0.1 * torch.randn(1, 1296, 43, 8, 16, device=dev)).requires_grad_(True)
+    nb2 = 4.0 * (B * 1296 * 8 + 1296 * 43 * 128 + B * 43 * 16)
+    timeit('routing fwd C=43 N=1296 R=%d' % B, lambda: ops.routing(u.detach(), W2.detach(), 3), None, nb2)
+    v2 = ops.routing(u, W2, 3)
+    gv2 = torch.randn_like(v2)
+    timeit('routing fwd+bwd C=43', lambda: torch.autograd.grad(ops.routing(u, W2, 3), (u, W2), gv2))
