@@ -80,6 +80,7 @@ def _x_geometry(x, nchw):
 
 def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv'):
     """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
+    x, weight = _f32(x, 'conv input'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     Cout = weight.shape[0]
     Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
@@ -98,14 +99,13 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
     return z
 
 
-def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
-    """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride."""
-    B, Hi, Wi, Cin = in_shape
-    _, Ho, Wo, Cout = dz.shape
-    st = _stream()
-    dx = _empty((B, Hi, Wi, Cin), dz)
-    covered = True
-    wp = _empty((query('cy_conv_packed_floats', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dz)
+def dgrad_classes(Hi, Wi, k, stride, pad):
+    """Input-gradient plan: one implicit GEMM per output-parity class (py, px) of the stride.
+
+    Input pixel y = stride*oy' + py receives dz[oy' + dy0 - a] * W[kh0 + stride*a] for a in range(TH)
+    (forward relation y = oy*stride - pad + kh).  Returns dicts with the cy_conv_gemm_t / cy_conv_pack_weights
+    fields of each non-empty class; raises if some input pixel has no tap at all (kernel < stride)."""
+    out = []
     for py in range(stride):
         kh0 = (py + pad) % stride
         TH = len(range(kh0, k, stride))
@@ -116,22 +116,37 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
             if Hv <= 0 or Wv <= 0:
                 continue
             if TH == 0 or TW == 0:
-                covered = False
-                continue
-            call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, TH, TW, kh0, kw0, stride, 1, st)
-            a = ConvGemm(X=dz.data_ptr(), Wp=wp.data_ptr(), Y=dx.data_ptr(), bias=None, stats=None,
-                         xs_b=Ho * Wo * Cout, xs_y=Wo * Cout, xs_x=Cout, xs_c=1, B=B, Hi=Ho, Wi=Wo, Cin=Cout,
-                         Ho=Hv, Wo=Wv, N=Cin, TH=TH, TW=TW, in_stride=1,
-                         dy0=(py + pad - kh0) // stride, dx0=(px + pad - kw0) // stride, dstep=-1,
-                         Hy=Hi, Wy=Wi, out_stride=stride, out_oy=py, out_ox=px, act=0)
-            with timer.range('conv_gemm_dgrad/' + tag):
-                call('cy_conv_gemm', C.byref(a), st)
-    if not covered:
-        raise _lib.HipExtensionError('conv_dgrad: kernel %d / stride %d leaves input pixels without taps' % (k, stride))
+                raise _lib.HipExtensionError('conv_dgrad: kernel %d / stride %d leaves input pixels without taps'
+                                             % (k, stride))
+            out.append(dict(TH=TH, TW=TW, kh0=kh0, kw0=kw0, kstep=stride, Ho=Hv, Wo=Wv,
+                            dy0=(py + pad - kh0) // stride, dx0=(px + pad - kw0) // stride, dstep=-1,
+                            out_stride=stride, out_oy=py, out_ox=px))
+    return out
+
+
+def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
+    """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride."""
+    dz, weight = _f32(dz, 'grad'), _f32(weight, 'conv weight')
+    B, Hi, Wi, Cin = in_shape
+    _, Ho, Wo, Cout = dz.shape
+    st = _stream()
+    dx = _empty((B, Hi, Wi, Cin), dz)
+    wp = _empty((query('cy_conv_packed_floats', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dz)
+    for c in dgrad_classes(Hi, Wi, k, stride, pad):
+        call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, c['TH'], c['TW'], c['kh0'], c['kw0'],
+             c['kstep'], 1, st)
+        a = ConvGemm(X=dz.data_ptr(), Wp=wp.data_ptr(), Y=dx.data_ptr(), bias=None, stats=None,
+                     xs_b=Ho * Wo * Cout, xs_y=Wo * Cout, xs_x=Cout, xs_c=1, B=B, Hi=Ho, Wi=Wo, Cin=Cout,
+                     Ho=c['Ho'], Wo=c['Wo'], N=Cin, TH=c['TH'], TW=c['TW'], in_stride=1,
+                     dy0=c['dy0'], dx0=c['dx0'], dstep=c['dstep'],
+                     Hy=Hi, Wy=Wi, out_stride=c['out_stride'], out_oy=c['out_oy'], out_ox=c['out_ox'], act=0)
+        with timer.range('conv_gemm_dgrad/' + tag):
+            call('cy_conv_gemm', C.byref(a), st)
     return dx
 
 
 def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
+    x, dz = _f32(x, 'conv input'), _f32(dz, 'grad')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     _, Ho, Wo, Cout = dz.shape
     st = _stream()

@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Drop-in for the reference's ``python main.py --model <name> --mode train|overfit|predict`` (main.py:22-373)
+on the MI355X-native hot path.
+
+Same flags (including the inverted ``--recon`` store_false, main.py:32), same ``experiments/<model>/params.json``
+keys, same registry shape ``name -> (ModelCls, loss_fn, predict_fn, metric)`` (main.py:258-265), same step loop
+(main.py:55-80) and the same artefacts (checkpoints, ``losses_tr.npy`` / ``losses_ev.npy``).  New, optional:
+  --synthetic N     train on N synthetic GTSRB/GTSDB-shaped samples (the reference ships no data)
+  --n_epochs E      override params.json
+  params.json key ``n_iter`` (routing iterations, default 3)
+Data-parallel: launch with ``python -m torch.distributed.run --nproc-per-node N main.py ...``; every rank takes
+its shard of each global batch and gradients are averaged with one RCCL all-reduce per step.
+Metrics (metrics.py), tensorboardX and torchsummary are outside the hot path; the metric slot of the registry is
+kept and ``--no_metric`` behaviour is the default when no metric implementation is registered.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import capsyolo_amd  # noqa: E402,F401
+from capsyolo_amd import config, dp, synth, utils  # noqa: E402
+from capsyolo_amd.loss_fns import capsule_loss, cnn_loss, dark_loss, darkcapsule_loss  # noqa: E402
+from capsyolo_amd.models import CapsuleNet, ConvNet, DarkCapsuleNet, DarkNet  # noqa: E402
+from capsyolo_amd.optim import Adam  # noqa: E402
+from capsyolo_amd.predict_fns import class_pred, dark_forward  # noqa: E402
+
+parser = argparse.ArgumentParser()
+parser.add_argument('--model', default='cnn', help=' | '.join(config.model_names))
+parser.add_argument('--mode', default='train', help='train | predict | overfit')
+parser.add_argument('--summary', default=True, help='if summarize model', action='store_true')
+parser.add_argument('--seed', type=int, default=0, help='random seed')
+parser.add_argument('--lr', type=float, default=1e-3, help='learning rate')
+parser.add_argument('--dropout', type=float, default=-1, help='dropout rate')
+parser.add_argument('--train_frac', type=float, default=1, help='fraction of train data')
+parser.add_argument('--restore', default=None, help="last | best")
+parser.add_argument('--combine', default=None, help="darknet_r | darknet_d")
+parser.add_argument('--recon', help='if use reconstruction loss', action='store_false')
+parser.add_argument('--recon_coef', default=5e-4, help='reconstruction coefficient')
+parser.add_argument('--eval_every', default=1, type=int, help='evaluate metric every # epochs')
+parser.add_argument('--fine_tune', default=-1, type=int, help='number of fixed layer in fine tuning')
+parser.add_argument('--no_metric', help='do not compute metric', action='store_true')
+parser.add_argument('--model_dir', default=None, help='model dir')
+parser.add_argument('--show', default=False, help='save result', action='store_true')
+parser.add_argument('--npy', default=False, help='data is npy file', action='store_true')
+parser.add_argument('--synthetic', type=int, default=0, help='use N synthetic samples instead of data/')
+parser.add_argument('--n_epochs', type=int, default=0, help='override params.json n_epochs')
+
+model_loss_predict = {
+    'cnn': (ConvNet, cnn_loss, class_pred, None),
+    'capsule': (CapsuleNet, capsule_loss, class_pred, None),
+    'darknet_d': (DarkNet, dark_loss, dark_forward, None),
+    'darknet_r': (DarkNet, dark_loss, dark_forward, None),
+    'darkcapsule': (DarkCapsuleNet, darkcapsule_loss, None, None),
+}
+
+
+def _batches(x, y, batch_size):
+    n_batch = (len(y) + batch_size - 1) // batch_size
+    return n_batch, zip(np.array_split(x, n_batch), np.array_split(y, n_batch))        # main.py:45-47
+
+
+def _to_device(x_bch, y_bch, params):
+    rank, world = params.rank, params.world
+    if world > 1:                                   # this rank's contiguous shard of the global batch
+        per = len(y_bch) // world
+        x_bch, y_bch = x_bch[rank * per:(rank + 1) * per], y_bch[rank * per:(rank + 1) * per]
+    x_t = torch.from_numpy(np.ascontiguousarray(x_bch)).float().permute(0, 3, 1, 2).contiguous().to(device=params.device)
+    return x_t, torch.from_numpy(np.ascontiguousarray(y_bch)).to(device=params.device)
+
+
+def _forward(model, loss_fn, x_bch, y_bch, params):
+    if params.model == 'capsule' and params.recon:                                       # main.py:61-66
+        y_hat, recon = model(x_bch, y_bch, True)
+        return y_hat, loss_fn(y_hat, y_bch, params, x_bch, recon)
+    y_hat = model(x_bch)
+    return y_hat, loss_fn(y_hat, y_bch, params)
+
+
+def train(x, y, model, optimizer, loss_fn, metric, params, bucket):
+    """main.py:42-95."""
+    model.train()
+    x, y = utils.shuffle(x, y)
+    n_batch, it = _batches(x, y, params.batch_size)
+    avg_loss, avg_iou, y_hat = 0.0, 0.0, []
+    for x_np, y_np in it:
+        x_bch, y_bch = _to_device(x_np, y_np, params)
+        y_hat_bch, loss = _forward(model, loss_fn, x_bch, y_bch, params)
+        y_hat.append(y_hat_bch.data.cpu().numpy())
+        optimizer.zero_grad()
+        loss.backward()
+        bucket.allreduce_mean()
+        optimizer.step()
+        avg_loss += loss.item() / n_batch
+        if params.model == 'darknet_d':
+            avg_iou += params.avg_iou.item() / n_batch
+    return avg_loss, -1
+
+
+def evaluate(x, y, model, loss_fn, metric, params):
+    """main.py:98-143."""
+    model.eval()
+    n_batch, it = _batches(x, y, params.batch_size)
+    avg_loss = 0.0
+    with torch.no_grad():
+        for x_np, y_np in it:
+            x_bch, y_bch = _to_device(x_np, y_np, params)
+            _, loss = _forward(model, loss_fn, x_bch, y_bch, params)
+            avg_loss += loss.item() / n_batch
+    return avg_loss, -1
+
+
+def train_and_evaluate(model, optimizer, loss_fn, metric, params, data, model_dir, restore_file=None):
+    """main.py:146-217."""
+    if restore_file is not None:
+        utils.load_checkpoint(os.path.join(model_dir, restore_file + '.pth.tar'), model, params, optimizer)
+    x_tr, y_tr, x_ev, y_ev = data
+    to_frac = int(y_tr.shape[0] * params.train_frac)
+    x_tr, y_tr = x_tr[:to_frac], y_tr[:to_frac]
+    scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'min', factor=params.lr_decay)
+    bucket = dp.GradBucket(model)
+    losses_tr, losses_ev, best_metric_ev = [], [], float('-inf')
+    for epoch in range(params.n_epochs):
+        loss_tr, _ = train(x_tr, y_tr, model, optimizer, loss_fn, metric, params, bucket)
+        loss_ev, metric_ev = evaluate(x_ev, y_ev, model, loss_fn, metric, params)
+        scheduler.step(loss_tr)
+        if params.rank == 0:
+            is_best = metric_ev > best_metric_ev
+            utils.save_checkpoint({'epoch': epoch + 1, 'state_dict': model.state_dict(),
+                                   'optim_dict': optimizer.state_dict()}, is_best=is_best, checkpoint=model_dir)
+            best_metric_ev = max(best_metric_ev, metric_ev)
+            print('epoch {} | train loss: {:05.3f} | eval loss: {:05.3f}'.format(epoch + 1, loss_tr, loss_ev), flush=True)
+            losses_tr.append(loss_tr)
+            losses_ev.append(loss_ev)
+            np.save(os.path.join(model_dir, 'losses_tr'), losses_tr)
+            np.save(os.path.join(model_dir, 'losses_ev'), losses_ev)
+    return losses_tr, losses_ev
+
+
+def load_params(model_dir, args):
+    """main.py:227-241 (params.device is decided here, the JSON value is ignored)."""
+    params = utils.Params(os.path.join(model_dir, 'params.json'))
+    params.device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    params.seed = args.seed
+    if args.dropout >= 0:
+        params.dropout = args.dropout
+    if not hasattr(params, 'dropout'):
+        params.dropout = 0.0
+    params.model = args.model
+    params.recon = args.recon
+    params.recon_coef = float(args.recon_coef)
+    params.eval_every = args.eval_every
+    params.train_frac = args.train_frac
+    if args.n_epochs:
+        params.n_epochs = args.n_epochs
+    return params
+
+
+def synthetic_data(args, params):
+    n = args.synthetic
+    n_ev = max(params.batch_size, n // 4)
+    if args.model in ('cnn', 'capsule'):
+        mk = lambda k, first: (synth.images(k, 32, first=first), synth.gtsrb_labels(k, params.n_classes, first=first))
+    else:
+        if params.darknet_input != 32 * params.n_grid and args.model == 'darkcapsule':
+            raise SystemExit('darkcapsule needs darknet_input = 32 * n_grid (models.py:393); got %d and %d'
+                             % (params.darknet_input, params.n_grid))
+        mk = lambda k, first: (synth.images(k, params.darknet_input, first=first),
+                               synth.gtsdb_labels(k, params.n_grid, params.n_classes, first=first))
+    x_tr, y_tr = mk(n, 0)
+    x_ev, y_ev = mk(n_ev, n)
+    return x_tr, y_tr, x_ev, y_ev
+
+
+def main(argv=None):
+    args = parser.parse_args(argv)
+    if args.model not in config.model_names:
+        print("Did not recognize model, choose from: ", *config.model_names)
+        sys.exit()
+    data_dir, model_dir = config.data_dir[args.model], config.model_dir[args.model]
+    if args.model_dir is not None:
+        model_dir = args.model_dir
+    params = load_params(model_dir, args)
+    params.rank, params.world, local_rank = dp.init_from_env()
+    if params.device == 'cuda':
+        torch.cuda.set_device(local_rank)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    if params.device == 'cuda':
+        torch.cuda.manual_seed(args.seed)
+    elif args.model != 'cnn':
+        raise SystemExit('model %s runs on hand-written gfx950 kernels only; no GPU is visible' % args.model)
+
+    model_cls, loss_fn, predict_fn, metric = model_loss_predict[args.model]
+    model = model_cls(params).to(device=params.device)
+    dp.broadcast_parameters(model)
+    if args.fine_tune > 0:
+        model.load_weights('./darknet19_weights.npz', 18)                              # main.py:273-278
+        for name, param in model.named_parameters():
+            if int(name.split('.')[1].split('_')[1]) <= params.fine_tune:
+                param.requires_grad = False
+    trainable = [p for p in model.parameters() if p.requires_grad]
+    optimizer = torch.optim.Adam(trainable, lr=args.lr) if args.model == 'cnn' else Adam(trainable, lr=args.lr)
+
+    if args.mode in ('train', 'overfit'):
+        if args.synthetic:
+            data = synthetic_data(args, params)
+        else:
+            if args.mode == 'overfit':
+                raise SystemExit('--mode overfit needs the real dataset under %s (or use --synthetic 3)' % data_dir)
+            data = utils.load_data(data_dir, False, npy=args.npy)
+        return train_and_evaluate(model, optimizer, loss_fn, metric, params, data, model_dir, restore_file=args.restore)
+    if args.mode == 'predict':
+        raise SystemExit('predict mode needs the raw GTSDB images and cv2 post-processing (out of scope, SURVEY section 2); '
+                         'the eval-mode forward is capsyolo_amd.predict_fns.class_pred / dark_forward')
+
+
+if __name__ == '__main__':
+    main()

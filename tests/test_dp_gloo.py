@@ -1,0 +1,59 @@
+"""Data-parallel glue on CPU: world_size 2 over gloo (the N>1 path of bench.py / main.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import REPO  # noqa: F401
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    import capsyolo_amd  # noqa: F401
+    from capsyolo_amd import dp, synth
+    r, w, _ = dp.init_from_env('gloo')
+    assert (r, w) == (rank, world) and dp.world_size() == world
+    torch.manual_seed(100 + rank)                      # replicas start different ...
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    for q in net[3].parameters():                      # an unused head: grad stays None (like the unused decoder)
+        q.requires_grad_(True)
+    dp.broadcast_parameters(net)                       # ... and are made identical
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3), torch.nn.Linear(3, 2))
+    ref.load_state_dict(net.state_dict())
+    # global batch of 8, this rank's shard of 4; loss = mean over the local batch (like the reference's /B)
+    xg = torch.from_numpy(synth.images(8, 2).reshape(8, -1)[:, :6].copy())
+    lo, hi = dp.shard_range(8, rank, world)
+    out = net[:3](xg[lo:hi])
+    (out ** 2).sum(dim=1).mean().backward()
+    bucket = dp.GradBucket(net)
+    n = bucket.allreduce_mean()
+    assert n == sum(q.numel() for q in net[:3].parameters())
+    (ref[:3](xg) ** 2).sum(dim=1).mean().backward()    # single-process gradient of the whole global batch
+    for a, b in zip(net[:3].parameters(), ref[:3].parameters()):
+        np.testing.assert_allclose(a.grad.numpy(), b.grad.numpy(), rtol=1e-5, atol=1e-6)
+    assert all(q.grad is None for q in net[3].parameters())
+    with pytest.raises(ValueError):
+        dp.shard_range(9, rank, world)
+    dist.barrier()
+    dist.destroy_process_group()
+    open(os.path.join(tmpdir, 'ok%d' % rank), 'w').write('ok')
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / 'ok0').exists() and (tmp_path / 'ok1').exists()
+
+
+def test_single_process_is_a_noop():
+    import capsyolo_amd  # noqa: F401
+    from capsyolo_amd import dp
+    net = torch.nn.Linear(3, 2)
+    net(torch.ones(1, 3)).sum().backward()
+    g = net.weight.grad.clone()
+    assert dp.GradBucket(net).allreduce_mean() == 0 and torch.equal(net.weight.grad, g)
+    assert dp.shard_range(32, 0, 1) == (0, 32)

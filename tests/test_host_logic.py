@@ -1,0 +1,163 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the product path has no
+fallback and never touches the oracle, host-side geometry / batching / checkpoint / parameter logic."""
+import os
+import re
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import REPO, make_params
+
+import capsyolo_amd  # noqa: F401
+from capsyolo_amd import _lib, config, models, ops, synth, utils
+from oracle import models as OM
+
+PKG = os.path.join(REPO, 'cs231-capsule-yolo-traffic-sign-detection_amd')
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    header = open(os.path.join(REPO, 'include', 'capsyolo_hip.h')).read()
+    declared = set(re.findall(r'\b((?:cy|capsyolo)_[a-z0-9_]+)\s*\(', header))
+    declared = {d for d in declared if not d.endswith('_t')}
+    assert len(declared) >= 35
+    lib = _lib.load()                                  # loads without a GPU; no compute call is made here
+    for name in sorted(declared):
+        assert hasattr(lib, name), 'libcapsyolo_hip.so does not export %s' % name
+    assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
+    assert lib.capsyolo_abi_version() == 1
+
+
+def test_ctypes_structs_match_header_field_order():
+    header = open(os.path.join(REPO, 'include', 'capsyolo_hip.h')).read()
+    for cname, struct in (('cy_conv_gemm_t', _lib.ConvGemm), ('cy_conv_wgrad_t', _lib.ConvWgrad),
+                          ('cy_routing_fwd_t', _lib.RoutingFwd), ('cy_routing_bwd_t', _lib.RoutingBwd)):
+        body = re.search(r'typedef struct \{([^{}]*)\}\s*%s;' % cname, header, re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        fields = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(',')
+            first = names[0].split()[-1].lstrip('*')
+            fields.append(first)
+            fields.extend(n.strip().lstrip('*') for n in names[1:])
+        assert fields == [f[0] for f in struct._fields_], cname
+
+
+def test_product_never_imports_the_oracle_and_has_no_fallback():
+    for root, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r'^\s*(from|import)\s+oracle', src, re.M), f
+    # a CPU tensor is rejected loudly, not silently computed some other way
+    with pytest.raises(_lib.HipExtensionError):
+        ops.conv_forward(torch.zeros(1, 4, 4, 32), torch.zeros(32, 32, 3, 3), None, 3, 1, 1)
+    with pytest.raises(_lib.HipExtensionError):
+        ops.routing(torch.zeros(2, 8, 8), torch.zeros(1, 8, 3, 8, 16))
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', os.path.join(PKG, 'does_not_exist.so'))
+    with pytest.raises(_lib.HipExtensionError, match='no CPU fallback'):
+        _lib.load()
+
+
+@pytest.mark.parametrize('k,stride,pad,Hi', [(3, 1, 1, 7), (4, 2, 1, 8), (8, 2, 0, 12), (1, 1, 0, 5), (3, 2, 1, 9),
+                                             (9, 1, 0, 11), (5, 3, 2, 10)])
+def test_dgrad_class_decomposition(k, stride, pad, Hi):
+    """numpy emulation of the cy_conv_gemm contract fed with ops.dgrad_classes must equal conv_transpose."""
+    rng = np.random.default_rng(k * 10 + stride)
+    Cin, Cout = 2, 3
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    W = rng.standard_normal((Cout, Cin, k, k))
+    dz = rng.standard_normal((1, Cout, Ho, Ho))
+    ref = F.conv_transpose2d(torch.from_numpy(dz), torch.from_numpy(W), stride=stride, padding=pad,
+                             output_padding=Hi - ((Ho - 1) * stride - 2 * pad + k)).numpy()
+    dx = np.full((1, Cin, Hi, Hi), np.nan)
+    for c in ops.dgrad_classes(Hi, Hi, k, stride, pad):
+        for oy in range(c['Ho']):
+            for ox in range(c['Wo']):
+                acc = np.zeros(Cin)
+                for a in range(c['TH']):
+                    for b in range(c['TW']):
+                        iy, ix = oy + c['dy0'] + a * c['dstep'], ox + c['dx0'] + b * c['dstep']
+                        if 0 <= iy < Ho and 0 <= ix < Ho:
+                            acc += dz[0, :, iy, ix] @ W[:, :, c['kh0'] + a * c['kstep'], c['kw0'] + b * c['kstep']]
+                dx[0, :, oy * c['out_stride'] + c['out_oy'], ox * c['out_stride'] + c['out_ox']] = acc
+    assert not np.isnan(dx).any()                      # every input pixel belongs to exactly one class
+    np.testing.assert_allclose(dx, ref, rtol=1e-12, atol=1e-12)
+
+
+def test_state_dict_keys_and_shapes_match_the_oracle():
+    p = make_params(n_grid=2)
+    pairs = [(models.DarkCapsuleNet(p), OM.DarkCapsuleNet(p)), (models.CapsuleNet(p), OM.CapsuleNet(p)),
+             (models.DarkNet(make_params(n_boxes=2, n_classes=0)), OM.DarkNet(make_params(n_boxes=2, n_classes=0))),
+             (models.DarkCapsuleNet3(make_params(n_classes=3)), OM.DarkCapsuleNet3(make_params(n_classes=3))),
+             (models.ConvNet(p), OM.ConvNet(p))]
+    for ours, ref in pairs:
+        a, b = ours.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys()), type(ours).__name__
+        for k in a:
+            assert a[k].shape == b[k].shape and a[k].dtype == b[k].dtype, k
+        ours.load_state_dict(b)                       # reference-format checkpoints load unchanged
+
+
+def test_params_checkpoint_and_batching(tmp_path):
+    pj = tmp_path / 'params.json'
+    pj.write_text('{"batch_size": 32, "n_classes": 43, "lr_decay": 0.1}')
+    params = utils.Params(str(pj))
+    assert params.batch_size == 32 and params.dict['n_classes'] == 43
+    net = models.DarkCapsuleNet(make_params())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-3)
+    utils.save_checkpoint({'epoch': 1, 'state_dict': net.state_dict(), 'optim_dict': opt.state_dict()}, True,
+                          str(tmp_path / 'ck'))
+    assert (tmp_path / 'ck' / 'last.pth.tar').exists() and (tmp_path / 'ck' / 'best.pth.tar').exists()
+    net2 = models.DarkCapsuleNet(make_params())
+    ck = utils.load_checkpoint(str(tmp_path / 'ck' / 'last.pth.tar'), net2, params)
+    assert ck['epoch'] == 1
+    for a, b in zip(net.state_dict().values(), net2.state_dict().values()):
+        assert torch.equal(a, b)
+    with pytest.raises(FileNotFoundError):
+        utils.load_checkpoint(str(tmp_path / 'nope.pth.tar'), net2, params)
+    # main.py:45-47 batching: near-equal splits
+    x, y = np.zeros((600, 2)), np.arange(600)
+    n_batch = (600 + 31) // 32
+    sizes = [len(b) for b in np.array_split(y, n_batch)]
+    assert n_batch == 19 and sizes == [32] * 11 + [31] * 8
+    np.random.seed(0)
+    xs, ys = utils.shuffle(x, y)
+    assert sorted(ys.tolist()) == list(range(600))
+
+
+def test_synthetic_data_shapes_and_world_size_independence():
+    x = synth.images(4, 64)
+    assert x.shape == (4, 64, 64, 3) and x.dtype == np.float32 and -1.0 <= x.min() and x.max() < 1.0
+    y = synth.gtsdb_labels(6, 13, 43)
+    assert y.shape == (6, 13, 13, 48) and y.dtype == np.float64
+    n_obj = (y[..., 0] == 1).sum(axis=(1, 2))
+    assert ((n_obj >= 1) & (n_obj <= 3)).all() and (y[y[..., 0] == 1][:, 5:].sum(axis=1) == 1).all()
+    # shards of a global batch equal slices of the single-process batch
+    np.testing.assert_array_equal(synth.images(4, 32, first=4), synth.images(8, 32)[4:])
+    np.testing.assert_array_equal(synth.gtsdb_labels(3, 7, 43, first=2), synth.gtsdb_labels(5, 7, 43)[2:])
+    np.testing.assert_array_equal(synth.gtsrb_labels(3, first=5), synth.gtsrb_labels(8)[5:])
+
+
+def test_registry_and_cli_surface():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('cy_main', os.path.join(REPO, 'main.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert set(m.model_loss_predict) == set(config.model_names)
+    args = m.parser.parse_args(['--model', 'darkcapsule', '--recon', '--no_metric'])
+    assert args.recon is False and args.no_metric is True and args.lr == 1e-3         # store_false semantics kept
+    assert m.parser.parse_args([]).recon is True
+    for name in config.model_names:
+        assert os.path.exists(os.path.join(REPO, config.model_dir[name], 'params.json'))
+    p = m.load_params(os.path.join(REPO, 'experiments', 'darkcapsule_416'), args)
+    assert p.n_grid == 13 and p.darknet_input == 416 and p.n_iter == 3 and p.recon is False
