@@ -32,14 +32,37 @@ static inline int cy_allow_lds(K kernel, size_t bytes) {
   return 0;
 }
 
-// wave64 butterfly sum (all lanes end with the total)
+// wave64 reductions on the DPP cross-lane network (no LDS round trips; __shfl_xor lowers to ds_bpermute_b32,
+// ~100 cycles each and serialised by its s_waitcnt): quad swaps, half-row / row mirrors, then row broadcasts
+// 15 and 31 leave the total in lane 63, which v_readlane returns to every lane as a scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get(float fallback, float src) {
+  return __int_as_float(
+      __builtin_amdgcn_update_dpp(__float_as_int(fallback), __float_as_int(src), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  v += dpp_get<0xB1, 0xF>(0.f, v);     // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF>(0.f, v);     // quad_perm [2,3,0,1]
+  v += dpp_get<0x141, 0xF>(0.f, v);    // row_half_mirror
+  v += dpp_get<0x140, 0xF>(0.f, v);    // row_mirror          -> every lane: sum of its 16-lane row
+  v += dpp_get<0x142, 0xA>(0.f, v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC>(0.f, v);    // row_bcast:31 into rows 2 and 3 -> lane 63: total
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// sum over each 16-lane row only (4 DPP steps); every lane of a row ends with its row's sum
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_get<0xB1, 0xF>(0.f, v);
+  v += dpp_get<0x4E, 0xF>(0.f, v);
+  v += dpp_get<0x141, 0xF>(0.f, v);
+  v += dpp_get<0x140, 0xF>(0.f, v);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
+  v = fmaxf(v, dpp_get<0xB1, 0xF>(v, v));
+  v = fmaxf(v, dpp_get<0x4E, 0xF>(v, v));
+  v = fmaxf(v, dpp_get<0x141, 0xF>(v, v));
+  v = fmaxf(v, dpp_get<0x140, 0xF>(v, v));
+  v = fmaxf(v, dpp_get<0x142, 0xA>(v, v));
+  v = fmaxf(v, dpp_get<0x143, 0xC>(v, v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }

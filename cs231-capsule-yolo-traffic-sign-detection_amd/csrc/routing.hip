@@ -56,160 +56,237 @@ __device__ __forceinline__ long long out_row(int row, int g, int B) {
   const int k = row / B, b = row - k * B;
   return (long long)b * g * g + k;
 }
-// offset of quarter w (1024 floats) of row `row` when N*Din == 4096
+// offset of quarter w (1024 floats) of row `row` when N*Din == 4096 (GATHER chosen at compile time so that the
+// streaming loops stay straight-line code)
+template <bool GATHER>
 __device__ __forceinline__ long long quarter_offset(int row, int w, int g, int B) {
-  if (g == 0) return (long long)row * 4096 + w * 1024;
-  const int k = row / B, b = row - k * B;
+  if (!GATHER) return (long long)row * 4096 + w * 1024;
+  const unsigned k = (unsigned)row / (unsigned)B, b = (unsigned)row - k * (unsigned)B;
   return ((long long)b * 16 * g * g + (long long)w * 4 * g * g + 4 * k) * 256;
+}
+template <bool GATHER>
+__device__ __forceinline__ long long out_row_t(int row, int g, int B) {
+  if (!GATHER) return row;
+  const unsigned k = (unsigned)row / (unsigned)B, b = (unsigned)row - k * (unsigned)B;
+  return (long long)b * g * g + k;
 }
 
 // ================================================================================================ C == 1
-constexpr int C1_ROWS = 4;                  // rows in flight per block iteration
+// One persistent block of 8 waves per CU; block b owns a contiguous range of rows.  Wave (q = w & 3, s = w >> 2):
+// quarter q of the rows lo+s, lo+s+2, ...  The wave's 80 W values are loaded straight into registers (20
+// float4 per lane, 5 KiB contiguous per wave-instruction).  There is NO block barrier in the row loop: a wave
+// reduces its partial dot products to 16-lane row sums with DPP, lanes 15/31/47/63 drop them into the row's LDS
+// slot, and the wave whose LDS ticket is the fourth of that row finishes it (sum, squash, store).
+constexpr int C1_THREADS = 512;            // 8 waves: 4 quarters x 2 row slots
+constexpr int C1_SLOTS = C1_THREADS / 256;
+constexpr int C1_MAXROWS = 64;             // rows per block the LDS slot table can hold
 
 template <int DOUT>
-__global__ __launch_bounds__(256) void caps1_fwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
-                                                        float* __restrict__ v_out, float* __restrict__ s_out, int R,
-                                                        int g, int B) {
-  __shared__ float part[2][4][C1_ROWS][8];
-  const int t = threadIdx.x, lane = t & 63;
-  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  // W[e][o], e = w*1024 + j*256 + lane*4 + q
-  float wr[4][4][DOUT];
+__device__ __forceinline__ void c1_load_w(const float* __restrict__ W, float (&wr)[4][4][DOUT], int q, int lane) {
+  // element e = q*1024 + j*256 + lane*4 + qq  -> W[e][o] at W[e*DOUT + o]; 4 consecutive e = 4*DOUT floats
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+  for (int j = 0; j < 4; ++j) {
+    const float* src = W + (size_t)(q * 1024 + j * 256 + lane * 4) * DOUT;
+    float tmp[4 * DOUT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int o = 0; o < DOUT; ++o) wr[j][q][o] = W[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o];
-
-  const int ngroups = (R + C1_ROWS - 1) / C1_ROWS;
-  int buf = 0;
-  for (int grp = blockIdx.x; grp < ngroups; grp += gridDim.x, buf ^= 1) {
-    float4 x[C1_ROWS][4];
-#pragma unroll
-    for (int rr = 0; rr < C1_ROWS; ++rr) {
-      const int row = grp * C1_ROWS + rr;
-      if (row < R) {
-        const float4* src = (const float4*)(u + quarter_offset(row, w, g, B)) + lane;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[rr][j] = src[j * 64];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) x[rr][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+    for (int k = 0; k < DOUT; ++k) {
+      const f32x4 v = *(const f32x4*)(src + 4 * k);
+      tmp[4 * k] = v[0]; tmp[4 * k + 1] = v[1]; tmp[4 * k + 2] = v[2]; tmp[4 * k + 3] = v[3];
     }
 #pragma unroll
-    for (int rr = 0; rr < C1_ROWS; ++rr) {
-      float acc[DOUT];
+    for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-      for (int o = 0; o < DOUT; ++o) acc[o] = 0.f;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int o = 0; o < DOUT; ++o)
-          acc[o] += x[rr][j].x * wr[j][0][o] + x[rr][j].y * wr[j][1][o] + x[rr][j].z * wr[j][2][o] +
-                    x[rr][j].w * wr[j][3][o];
-#pragma unroll
-      for (int o = 0; o < DOUT; ++o) {
-        const float s = wave_sum(acc[o]);
-        if (lane == 0) part[buf][w][rr][o] = s;
-      }
-    }
-    __syncthreads();
-    if (t < C1_ROWS) {
-      const int row = grp * C1_ROWS + t;
-      if (row < R) {
-        float s[DOUT], v[DOUT];
-#pragma unroll
-        for (int o = 0; o < DOUT; ++o) s[o] = part[buf][0][t][o] + part[buf][1][t][o] + part[buf][2][t][o] + part[buf][3][t][o];
-        squash_vec(s, v, DOUT);
-#pragma unroll
-        for (int o = 0; o < DOUT; ++o) { s_out[(long long)row * DOUT + o] = s[o]; v_out[out_row(row, g, B) * DOUT + o] = v[o]; }
-      }
-    }
-    // the other LDS buffer is used next iteration; the barrier of that iteration orders its reuse
+      for (int o = 0; o < DOUT; ++o) wr[j][qq][o] = tmp[qq * DOUT + o];
   }
 }
 
-template <int DOUT>
-__global__ __launch_bounds__(256) void caps1_bwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
-                                                        const float* __restrict__ s_in, const float* __restrict__ dv,
-                                                        float* __restrict__ du, float* __restrict__ slabs, int R,
-                                                        int g, int B, int rows_per_block) {
+template <int DOUT, bool GATHER>
+__global__ __launch_bounds__(C1_THREADS, 2) void caps1_fwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
+                                                                  float* __restrict__ v_out, float* __restrict__ s_out,
+                                                                  int R, int g, int B) {
+  __shared__ float part[C1_MAXROWS][16][8];       // [row of the block][4 quarters x 4 lane-rows][DOUT (padded)]
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q = w & 3, sl = w >> 2;
+  const int lo = (int)((long long)R * blockIdx.x / gridDim.x), hi = (int)((long long)R * (blockIdx.x + 1) / gridDim.x);
+  // The row loop is straight-line VMEM: loads are unconditional (rows past the end are clamped to the block's
+  // last row and their results dropped) and nothing is stored to global memory inside it, so the compiler's
+  // s_waitcnt vmcnt(N) stays exact and the next row set remains in flight while this one is consumed.
+  f32x4 xa[4], xb[4];
+#define C1_LOAD_ROW(X, ROW)                                                                        \
+  {                                                                                                \
+    const int r_ = (ROW) < hi ? (ROW) : hi - 1;                                                    \
+    const f32x4* src_ = (const f32x4*)(u + quarter_offset<GATHER>(r_, q, g, B)) + lane;                    \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) X[j] = src_[j * 64];                             \
+  }
+#define C1_CONSUME(X, ROW)                                                                         \
+  {                                                                                                \
+    float acc[DOUT];                                                                               \
+    _Pragma("unroll") for (int o = 0; o < DOUT; ++o) acc[o] = 0.f;                                 \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                  \
+      _Pragma("unroll") for (int qq = 0; qq < 4; ++qq)                                             \
+        _Pragma("unroll") for (int o = 0; o < DOUT; ++o) acc[o] += X[j][qq] * wr[j][qq][o];        \
+    _Pragma("unroll") for (int o = 0; o < DOUT; ++o) acc[o] = row16_sum(acc[o]);                   \
+    if ((lane & 15) == 15 && (ROW) < hi) {                                                         \
+      float* dst_ = &part[(ROW) - lo][q * 4 + (lane >> 4)][0];                                     \
+      _Pragma("unroll") for (int o = 0; o < DOUT; ++o) dst_[o] = acc[o];                           \
+    }                                                                                              \
+  }
+  const int first = lo + sl;
+  C1_LOAD_ROW(xa, first)
+  C1_LOAD_ROW(xb, first + C1_SLOTS)
+  float wr[4][4][DOUT];
+  c1_load_w<DOUT>(W, wr, q, lane);
+  // drain the prologue's loads here, once: otherwise the loop header inherits "W may be pending" from the
+  // preheader and hipcc waits vmcnt(0) in every iteration, which would also drain the prefetched row set
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0), expcnt/lgkmcnt untouched
+  for (int row = first; row < hi; row += 2 * C1_SLOTS) {
+    C1_CONSUME(xa, row)
+    C1_LOAD_ROW(xa, row + 2 * C1_SLOTS)
+    C1_CONSUME(xb, row + C1_SLOTS)
+    C1_LOAD_ROW(xb, row + 3 * C1_SLOTS)
+  }
+#undef C1_LOAD_ROW
+#undef C1_CONSUME
+  __syncthreads();
+  // finish: thread -> (row = t/8, o = t%8): sum the 16 partial sums, squash over the row's DOUT values
+  {
+    const int rr = t >> 3, o = t & 7;
+    const int row = lo + rr;
+    if (rr < C1_MAXROWS) {
+      float sv = 0.f;
+      if (row < hi && o < DOUT) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sv += part[rr][k][o];
+      }
+      float n2 = sv * sv;                   // lanes o >= DOUT contribute 0
+      n2 += dpp_get<0xB1, 0xF>(0.f, n2);    // 8-lane groups: quad swaps + half-row mirror
+      n2 += dpp_get<0x4E, 0xF>(0.f, n2);
+      n2 += dpp_get<0x141, 0xF>(0.f, n2);
+      if (row < hi && o < DOUT) {
+        const float f = (n2 / (1.f + n2)) / sqrtf(n2);
+        s_out[(long long)row * DOUT + o] = sv;
+        v_out[out_row_t<GATHER>(row, g, B) * DOUT + o] = f * sv;
+      }
+    }
+  }
+}
+
+constexpr int C1B_THREADS = 512;
+// backward: du = W ds (written in place of the gather), dW = sum_rows u (x) ds accumulated in 80 registers per
+// lane; the two slots of a quarter are combined through LDS and each block writes ONE 4096*DOUT slab.
+template <int DOUT, bool GATHER>
+__global__ __launch_bounds__(C1B_THREADS, 2) void caps1_bwd_kernel(const float* __restrict__ u, const float* __restrict__ W,
+                                                                  const float* __restrict__ s_in, const float* __restrict__ dv,
+                                                                  float* __restrict__ du, float* __restrict__ slabs, int R,
+                                                                  int g, int B) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int t = threadIdx.x, lane = t & 63;
+  const int w = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int q = w & 3, sl = w >> 2;
+  const int lo = (int)((long long)R * blockIdx.x / gridDim.x), hi = (int)((long long)R * (blockIdx.x + 1) / gridDim.x);
   float wr[4][4][DOUT], dw[4][4][DOUT];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-      for (int o = 0; o < DOUT; ++o) {
-        wr[j][q][o] = W[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o];
-        dw[j][q][o] = 0.f;
-      }
-  const int r0 = blockIdx.x * rows_per_block;
-  const int r1 = min(R, r0 + rows_per_block);
-  for (int row = r0; row < r1; row += 2) {
-    const bool two = row + 1 < r1;
-    const long long off0 = quarter_offset(row, w, g, B);
-    const long long off1 = two ? quarter_offset(row + 1, w, g, B) : off0;
-    float4 x0[4], x1[4];
+      for (int o = 0; o < DOUT; ++o) dw[j][qq][o] = 0.f;
+
+  // this wave's rows: first, first+2, ... (n of them).  Same straight-line discipline as the forward kernel
+  // (unconditional clamped loads, every store belongs to a valid row, W drained once before the loop), but with
+  // ONE register set (wr + dw already take 160 VGPRs): as soon as the FMAs of float4 j are done, the same
+  // registers are re-loaded with float4 j of the wave's next row, so each load has 3/4 of a row's work to land.
+  const int first = lo + sl;
+  const int n = first < hi ? (hi - first + 1) / 2 : 0;
+  f32x4 x[4];
+  {
+    const f32x4* src = (const f32x4*)(u + quarter_offset<GATHER>(first < R ? first : R - 1, q, g, B)) + lane;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = src[j * 64];
+  }
+  c1_load_w<DOUT>(W, wr, q, lane);
+  __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): see caps1_fwd_kernel
+  for (int i = 0; i < n; ++i) {
+    const int row = first + 2 * i;
+    const int nrow = (i + 1 < n) ? row + 2 : row;           // clamped: the last row is simply read again
+    float sv[DOUT], dvv[DOUT], ds[DOUT];
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) {
+      sv[o] = s_in[(long long)row * DOUT + o];
+      dvv[o] = dv[out_row_t<GATHER>(row, g, B) * DOUT + o];
+    }
+    squash_bwd_vec(sv, dvv, ds, DOUT);
+    f32x4* dst = (f32x4*)(du + quarter_offset<GATHER>(row, q, g, B)) + lane;
+    const f32x4* nsrc = (const f32x4*)(u + quarter_offset<GATHER>(nrow, q, g, B)) + lane;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      x0[j] = ((const float4*)(u + off0))[lane + j * 64];
-      x1[j] = ((const float4*)(u + off1))[lane + j * 64];
-    }
-    float ds0[DOUT], ds1[DOUT];
-    {
-      float s[DOUT], d[DOUT];
+      f32x4 gq;
 #pragma unroll
-      for (int o = 0; o < DOUT; ++o) { s[o] = s_in[(long long)row * DOUT + o]; d[o] = dv[out_row(row, g, B) * DOUT + o]; }
-      squash_bwd_vec(s, d, ds0, DOUT);
-      const int rb = two ? row + 1 : row;
-#pragma unroll
-      for (int o = 0; o < DOUT; ++o) { s[o] = s_in[(long long)rb * DOUT + o]; d[o] = dv[out_row(rb, g, B) * DOUT + o]; }
-      squash_bwd_vec(s, d, ds1, DOUT);
-      if (!two) {
-#pragma unroll
-        for (int o = 0; o < DOUT; ++o) ds1[o] = 0.f;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float g0[4], g1[4];
-      const float xa[4] = {x0[j].x, x0[j].y, x0[j].z, x0[j].w};
-      const float xb[4] = {x1[j].x, x1[j].y, x1[j].z, x1[j].w};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float a0 = 0.f, a1 = 0.f;
+      for (int qq = 0; qq < 4; ++qq) {
+        float a0 = 0.f;
 #pragma unroll
         for (int o = 0; o < DOUT; ++o) {
-          a0 += wr[j][q][o] * ds0[o];
-          a1 += wr[j][q][o] * ds1[o];
-          dw[j][q][o] += xa[q] * ds0[o] + xb[q] * ds1[o];
+          a0 += wr[j][qq][o] * ds[o];
+          dw[j][qq][o] += x[j][qq] * ds[o];
         }
-        g0[q] = a0; g1[q] = a1;
+        gq[qq] = a0;
       }
-      ((float4*)(du + off0))[lane + j * 64] = make_float4(g0[0], g0[1], g0[2], g0[3]);
-      if (two) ((float4*)(du + off1))[lane + j * 64] = make_float4(g1[0], g1[1], g1[2], g1[3]);
+      x[j] = nsrc[j * 64];
+      dst[j * 64] = gq;
     }
   }
-  float* slab = slabs + (long long)blockIdx.x * 4096 * DOUT;
+  // slot 1 -> LDS, slot 0 adds and writes the block's slab (element-major: e*DOUT + o, like W)
+  __syncthreads();
+  if (sl == 1) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+      for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
-      for (int o = 0; o < DOUT; ++o) slab[(long long)(w * 1024 + j * 256 + lane * 4 + q) * DOUT + o] = dw[j][q][o];
+        for (int o = 0; o < DOUT; ++o) lds[(size_t)(q * 1024 + j * 256 + lane * 4 + qq) * DOUT + o] = dw[j][qq][o];
+  }
+  __syncthreads();
+  if (sl == 0) {
+    float* slab = slabs + (long long)blockIdx.x * 4096 * DOUT;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) {
+          const size_t idx = (size_t)(q * 1024 + j * 256 + lane * 4 + qq) * DOUT + o;
+          slab[idx] = dw[j][qq][o] + lds[idx];
+        }
+  }
 }
 
-__global__ void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslabs, long long n) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += slabs[(long long)k * n + i];
-  out[i] = s;
+// out[i] = sum_k slabs[k][i]: block = 64 outputs x 16 slab phases (1024 threads), coalesced 256-byte rows,
+// 4 independent loads in flight per thread
+__global__ __launch_bounds__(1024) void slab_sum_kernel(const float* __restrict__ slabs, float* __restrict__ out, int nslabs,
+                                                        long long n) {
+  __shared__ float red[16][64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + lane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (i < n) {
+    int k = ph;
+    for (; k + 48 < nslabs; k += 64) {
+      s0 += slabs[(long long)k * n + i];
+      s1 += slabs[(long long)(k + 16) * n + i];
+      s2 += slabs[(long long)(k + 32) * n + i];
+      s3 += slabs[(long long)(k + 48) * n + i];
+    }
+    for (; k < nslabs; k += 16) s0 += slabs[(long long)k * n + i];
+  }
+  red[ph][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && i < n) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][lane];
+    out[i] = s;
+  }
 }
 
 // ================================================================================================ general C
@@ -593,6 +670,7 @@ __global__ void length_bwd_kernel(const float* __restrict__ v, const float* __re
   for (int o = 0; o < D; ++o) dv[r * D + o] = k * v[r * D + o];
 }
 
+constexpr int C1_BLOCKS = 256;             // one persistent block per CU
 bool fast_c1(int N, int C, int Din, int Dout) { return C == 1 && N * Din == 4096 && Dout == 5; }
 
 template <int DIN, int DOUT>
@@ -646,10 +724,13 @@ extern "C" int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (fast_c1(a->N, a->C, a->Din, a->Dout)) {
-    const int groups = (a->R + C1_ROWS - 1) / C1_ROWS;
-    const int blocks = groups < 1024 ? groups : 1024;
+    int blocks = a->R < C1_BLOCKS ? a->R : C1_BLOCKS;
+    while ((a->R + blocks - 1) / blocks + 1 > C1_MAXROWS) blocks *= 2;   // keep rows per block within the slot table
     float* s_last = a->s_hist + (long long)(a->n_iter - 1) * a->R * 5;
-    caps1_fwd_kernel<5><<<blocks, 256, 0, s>>>(a->u, a->W, a->v_out, s_last, a->R, a->gather_g, a->gather_B);
+    if (a->gather_g)
+      caps1_fwd_kernel<5, true><<<blocks, C1_THREADS, 0, s>>>(a->u, a->W, a->v_out, s_last, a->R, a->gather_g, a->gather_B);
+    else
+      caps1_fwd_kernel<5, false><<<blocks, C1_THREADS, 0, s>>>(a->u, a->W, a->v_out, s_last, a->R, 0, 1);
   } else if (a->Dout == 5) rc = launch_fwd<8, 5>(a, s);
   else if (a->Dout == 16) rc = launch_fwd<8, 16>(a, s);
   else rc = launch_fwd<8, 21>(a, s);
@@ -660,7 +741,7 @@ extern "C" int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream) {
 
 extern "C" long long cy_routing_bwd_ws_floats(const cy_routing_bwd_t* a) {
   if (!a) return 0;
-  if (fast_c1(a->N, a->C, a->Din, a->Dout)) return 256ll * 4096 * 5;
+  if (fast_c1(a->N, a->C, a->Din, a->Dout)) return (long long)C1_BLOCKS * 4096 * 5;
   return 2ll * a->n_iter * a->R * a->C * a->Dout;
 }
 
@@ -670,16 +751,21 @@ extern "C" int cy_routing_bwd(const cy_routing_bwd_t* a, void* stream) {
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (fast_c1(a->N, a->C, a->Din, a->Dout)) {
-    int blocks = 256;
-    if (blocks > (a->R + 1) / 2) blocks = (a->R + 1) / 2;
-    int rpb = (a->R + blocks - 1) / blocks;
-    rpb = (rpb + 1) / 2 * 2;
-    blocks = (a->R + rpb - 1) / rpb;
+    const int blocks = a->R < C1_BLOCKS ? a->R : C1_BLOCKS;
+    const size_t lds = (size_t)4096 * 5 * 4;
     const float* s_last = a->s_hist + (long long)(a->n_iter - 1) * a->R * 5;
-    caps1_bwd_kernel<5><<<blocks, 256, 0, s>>>(a->u, a->W, s_last, a->dv, a->du, a->ws, a->R, a->gather_g, a->gather_B, rpb);
+    if (a->gather_g) {
+      rc = cy_allow_lds(caps1_bwd_kernel<5, true>, lds);
+      if (rc) return rc;
+      caps1_bwd_kernel<5, true><<<blocks, C1B_THREADS, lds, s>>>(a->u, a->W, s_last, a->dv, a->du, a->ws, a->R, a->gather_g, a->gather_B);
+    } else {
+      rc = cy_allow_lds(caps1_bwd_kernel<5, false>, lds);
+      if (rc) return rc;
+      caps1_bwd_kernel<5, false><<<blocks, C1B_THREADS, lds, s>>>(a->u, a->W, s_last, a->dv, a->du, a->ws, a->R, 0, 1);
+    }
     CY_LAUNCH_CHECK("cy_routing_bwd(c1)");
     const long long n = 4096ll * 5;
-    slab_sum_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(a->ws, a->dW, blocks, n);
+    slab_sum_kernel<<<(unsigned)cy_ceil_div(n, 64), 1024, 0, s>>>(a->ws, a->dW, blocks, n);
     CY_LAUNCH_CHECK("cy_routing_bwd(c1 reduce)");
     return 0;
   }
