@@ -34,7 +34,7 @@ class ConvWgrad(C.Structure):
 class RoutingFwd(C.Structure):
     _fields_ = [('u', C.c_void_p), ('W', C.c_void_p), ('v_out', C.c_void_p), ('s_hist', C.c_void_p),
                 ('R', C.c_int), ('N', C.c_int), ('C', C.c_int), ('Din', C.c_int), ('Dout', C.c_int),
-                ('n_iter', C.c_int), ('gather_g', C.c_int), ('gather_B', C.c_int)]
+                ('n_iter', C.c_int), ('gather_g', C.c_int), ('gather_B', C.c_int), ('ws', C.c_void_p)]
 
 
 class RoutingBwd(C.Structure):
@@ -87,6 +87,7 @@ _RET = {
     'cy_conv_packed_floats': (_L, [_I, _I]),
     'cy_conv_wgrad_ws_floats': (_L, [C.POINTER(ConvWgrad)]),
     'cy_routing_bwd_ws_floats': (_L, [C.POINTER(RoutingBwd)]),
+    'cy_routing_fwd_ws_floats': (_L, [C.POINTER(RoutingFwd)]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
 

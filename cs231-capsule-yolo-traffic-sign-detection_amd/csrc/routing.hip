@@ -542,14 +542,15 @@ __global__ __launch_bounds__(256) void routing_bwd_rows_kernel(cy_routing_bwd_t 
 }
 
 // ---- backward B2: wave <-> input capsule i, lanes <-> j; dW_i accumulated in registers over the rows
+constexpr int B2_WAVES = 4;                // input capsules (waves) per block; dW_i + u_hat need > 256 registers: one wave per SIMD
 template <int DIN, int DOUT>
-__global__ __launch_bounds__(256, 1) void routing_bwd_caps_kernel(cy_routing_bwd_t a, int rows_per_chunk) {
+__global__ __launch_bounds__(64 * B2_WAVES, 1) void routing_bwd_caps_kernel(cy_routing_bwd_t a, int rows_per_chunk) {
   using T = WTile<DIN, DOUT>;
-  extern __shared__ __attribute__((aligned(16))) float smem[];   // [4][C][WS]
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [B2_WAVES][C][WS]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int C = a.C, N = a.N, R = a.R, NT = a.n_iter;
-  const int i = blockIdx.x * 4 + wave;
+  const int i = blockIdx.x * B2_WAVES + wave;
   const bool iv = i < N;
   const bool jv = lane < C;
   const int jl = jv ? lane : 0;
@@ -563,7 +564,33 @@ __global__ __launch_bounds__(256, 1) void routing_bwd_caps_kernel(cy_routing_bwd
   // this wave's W_i -> its private LDS region (wave-local, but a block barrier keeps it simple)
   if (iv) {
     const float* Wi = a.W + (long long)i * C * T::DD;
-    for (int idx = lane; idx < C * T::DD; idx += 64) Wme[(idx / T::DD) * T::WS + idx % T::DD] = Wi[idx];
+    if (T::V4) {                            // 8 independent float4 loads in flight per lane
+      const int n4 = C * T::DD / 4;
+      for (int base = 0; base < n4; base += 64 * 8) {
+        f32x4 tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int idx = base + k * 64 + lane;
+          tmp[k] = idx < n4 ? ((const f32x4*)Wi)[idx] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int idx = base + k * 64 + lane;
+          if (idx < n4) *(f32x4*)(Wme + ((idx * 4) / T::DD) * T::WS + (idx * 4) % T::DD) = tmp[k];
+        }
+      }
+    } else {
+      for (int base = 0; base < C * T::DD; base += 64 * 8) {
+        float tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { const int idx = base + k * 64 + lane; tmp[k] = idx < C * T::DD ? Wi[idx] : 0.f; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int idx = base + k * 64 + lane;
+          if (idx < C * T::DD) Wme[(idx / T::DD) * T::WS + idx % T::DD] = tmp[k];
+        }
+      }
+    }
   }
   __syncthreads();
   const float* Wl = Wme + jl * T::WS;
@@ -588,8 +615,18 @@ __global__ __launch_bounds__(256, 1) void routing_bwd_caps_kernel(cy_routing_bwd
       for (int o = 0; o < DOUT; ++o) duh[o] = jv ? invC * ds_all[my + o] : 0.f;
       for (int it = 1; it < NT; ++it) {
         float Vt[DOUT], ds[DOUT];
+        if (DOUT % 4 == 0) {
 #pragma unroll
-        for (int o = 0; o < DOUT; ++o) { Vt[o] = V_all[(long long)it * plane + my + o]; ds[o] = ds_all[(long long)it * plane + my + o]; }
+          for (int o4 = 0; o4 < DOUT / 4; ++o4) {
+            const f32x4 a4 = *(const f32x4*)(V_all + (long long)it * plane + my + o4 * 4);
+            const f32x4 b4 = *(const f32x4*)(ds_all + (long long)it * plane + my + o4 * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { Vt[o4 * 4 + e] = a4[e]; ds[o4 * 4 + e] = b4[e]; }
+          }
+        } else {
+#pragma unroll
+          for (int o = 0; o < DOUT; ++o) { Vt[o] = V_all[(long long)it * plane + my + o]; ds[o] = ds_all[(long long)it * plane + my + o]; }
+        }
         float b = 0.f, dc = 0.f;
 #pragma unroll
         for (int o = 0; o < DOUT; ++o) { b += uh[0][o] * Vt[o]; dc += uh[0][o] * ds[o]; }
@@ -670,6 +707,198 @@ __global__ void length_bwd_kernel(const float* __restrict__ v, const float* __re
   for (int o = 0; o < D; ++o) dv[r * D + o] = k * v[r * D + o];
 }
 
+// ================================================================================================ small R: phased
+// With few rows the row decomposition above cannot fill the chip (R=32 -> 4 blocks), so the input capsules are
+// split into chunks as well: grid = (row blocks) x (chunks).  The sum over i then crosses blocks, which is a
+// grid-wide dependency once per routing iteration; on this chip a kernel boundary (~1.5 us) is cheaper than an
+// in-kernel grid barrier (4-10 us), so each iteration is one "phase" launch writing per-chunk partial sums plus
+// a tiny finish launch (sum over chunks, squash, V += v).  Same lane/wave roles and W staging as above.
+struct PhaseArgs {
+  const float* u; const float* W; const float* V; const float* ds; float* slab;
+  int R, N, C, it, ic, g, B;
+};
+
+template <int DIN, int DOUT, int RW, int MODE>   // MODE 0: forward partial s^t;  MODE 1: backward partial A_t
+__global__ __launch_bounds__(256, 2) void routing_phase_kernel(PhaseArgs a) {
+  using T = WTile<DIN, DOUT>;
+  extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][C][WS]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int C = a.C, N = a.N, R = a.R;
+  const int tile = C * T::WS;
+  const bool jv = lane < C;
+  const int jl = jv ? lane : 0;
+  const int row0 = (blockIdx.x * 4 + wave) * RW;
+  const int i0 = blockIdx.y * a.ic;
+  const int i1 = min(N, i0 + a.ic);
+  const long long CD = (long long)C * DOUT;
+  const float invC = 1.0f / (float)C;
+
+  float V[RW][DOUT], dsv[MODE == 1 ? RW : 1][DOUT], acc[RW][DOUT];
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = row0 + rr;
+    const bool ok = row < R && jv;
+    const long long my = (long long)(ok ? row : 0) * CD + (long long)jl * DOUT;
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) {
+      V[rr][o] = (ok && a.V != nullptr) ? a.V[my + o] : 0.f;
+      if (MODE == 1) dsv[rr][o] = ok ? a.ds[my + o] : 0.f;
+      acc[rr][o] = 0.f;
+    }
+  }
+  WStage<DIN, DOUT> stage;
+  stage.load(a.W + (long long)i0 * C * T::DD, C, t);
+  stage.store(smem, C, t);
+  __syncthreads();
+  for (int i = i0; i < i1; ++i) {
+    const int cur = (i - i0) & 1;
+    if (i + 1 < i1) stage.load(a.W + (long long)(i + 1) * C * T::DD, C, t);
+    const float* Wl = smem + cur * tile + jl * T::WS;
+    float uv[RW][DIN], uh[RW][DOUT];
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      const int row = row0 + rr;
+      if (row < R) {
+        const float* up = a.u + u_offset(row, i, N, DIN, a.g, a.B);
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) uv[rr][d] = up[d];
+      } else {
+#pragma unroll
+        for (int d = 0; d < DIN; ++d) uv[rr][d] = 0.f;
+      }
+    }
+    predict<DIN, DOUT, RW>(Wl, uv, uh);
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+      if (MODE == 0) {
+        float c = invC;
+        if (a.it > 0) {
+          float b = 0.f;
+#pragma unroll
+          for (int o = 0; o < DOUT; ++o) b += uh[rr][o] * V[rr][o];
+          b = jv ? b : -INFINITY;
+          const float m = wave_max(b);
+          const float e = jv ? expf(b - m) : 0.f;
+          c = e / wave_sum(e);
+        }
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) acc[rr][o] += c * uh[rr][o];
+      } else {
+        float b = 0.f, dc = 0.f;
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) { b += uh[rr][o] * V[rr][o]; dc += uh[rr][o] * dsv[rr][o]; }
+        b = jv ? b : -INFINITY;
+        const float m = wave_max(b);
+        const float e = jv ? expf(b - m) : 0.f;
+        const float c = e / wave_sum(e);
+        const float dot = wave_sum(c * dc);
+        const float db = c * (dc - dot);
+#pragma unroll
+        for (int o = 0; o < DOUT; ++o) acc[rr][o] += db * uh[rr][o];
+      }
+    }
+    if (i + 1 < i1) stage.store(smem + (cur ^ 1) * tile, C, t);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int rr = 0; rr < RW; ++rr) {
+    const int row = row0 + rr;
+    if (row < R && jv) {
+      float* dst = a.slab + ((long long)blockIdx.y * R + row) * CD + (long long)lane * DOUT;
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) dst[o] = acc[rr][o];
+    }
+  }
+}
+
+// forward finish of iteration `it` (s^t already summed over chunks into s_hist[it] by slab_sum_kernel):
+// v = squash(s), V (+)= v; thread <-> (row, j)
+template <int DOUT>
+__global__ void routing_fin_fwd_kernel(const float* __restrict__ s_hist_it, float* __restrict__ V,
+                                       float* __restrict__ v_out, int R, int C, int it, int last, int g, int B) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)R * C) return;
+  const int row = (int)(idx / C), j = (int)(idx - (long long)row * C);
+  const long long my = idx * DOUT;
+  float sv[DOUT], vv[DOUT];
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) sv[o] = s_hist_it[my + o];
+  squash_vec(sv, vv, DOUT);
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) V[my + o] = (it == 0 ? 0.f : V[my + o]) + vv[o];
+  if (last) {
+    float* vo = v_out + (out_row(row, g, B) * C + j) * DOUT;
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) vo[o] = vv[o];
+  }
+}
+
+// backward preparation: V_all[t] = sum_{tau<t} squash(s^tau), ds_all[T-1] = squash_bwd(s^{T-1}, dv), SA = 0
+template <int DOUT>
+__global__ void routing_bwd_prep_kernel(const float* __restrict__ s_hist, const float* __restrict__ dv,
+                                        float* __restrict__ ds_all, float* __restrict__ V_all, float* __restrict__ SA,
+                                        int R, int C, int NT, int g, int B) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)R * C) return;
+  const int row = (int)(idx / C), j = (int)(idx - (long long)row * C);
+  const long long plane = (long long)R * C * DOUT, my = idx * DOUT;
+  float Vt[DOUT], sv[DOUT], vv[DOUT];
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) Vt[o] = 0.f;
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int o = 0; o < DOUT; ++o) { V_all[(long long)t * plane + my + o] = Vt[o]; sv[o] = s_hist[(long long)t * plane + my + o]; }
+    if (t == NT - 1) {
+      float d[DOUT], ds[DOUT];
+      const float* dp = dv + (out_row(row, g, B) * C + j) * DOUT;
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) d[o] = dp[o];
+      squash_bwd_vec(sv, d, ds, DOUT);
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) { ds_all[(long long)t * plane + my + o] = ds[o]; SA[my + o] = 0.f; }
+    } else {
+      squash_vec(sv, vv, DOUT);
+#pragma unroll
+      for (int o = 0; o < DOUT; ++o) Vt[o] += vv[o];
+    }
+  }
+}
+
+// backward finish of step t (>= 1), A_t already summed over chunks into `At` by slab_sum_kernel:
+// SA += A_t ; ds_all[t-1] = squash_bwd(s^{t-1}, SA)
+template <int DOUT>
+__global__ void routing_bwd_fin_kernel(const float* __restrict__ At, const float* __restrict__ s_hist,
+                                       float* __restrict__ ds_all, float* __restrict__ SA, int R, int C, int t) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)R * C) return;
+  const long long plane = (long long)R * C * DOUT, my = idx * DOUT;
+  float sa[DOUT], sv[DOUT], ds[DOUT];
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) {
+    sa[o] = SA[my + o] + At[my + o];
+    SA[my + o] = sa[o];
+    sv[o] = s_hist[(long long)(t - 1) * plane + my + o];
+  }
+  squash_bwd_vec(sv, sa, ds, DOUT);
+#pragma unroll
+  for (int o = 0; o < DOUT; ++o) ds_all[(long long)(t - 1) * plane + my + o] = ds[o];
+}
+
+struct PhasePlan { bool phased; int row_blocks, nch, ic; };
+// rows per block of the fused single-launch kernel: 4 waves x RW rows
+inline PhasePlan plan_phases(int R, int N, int rw) {
+  PhasePlan p;
+  p.row_blocks = (R + 4 * rw - 1) / (4 * rw);
+  p.phased = p.row_blocks < 128;
+  int nch = (512 + p.row_blocks - 1) / p.row_blocks;
+  if (nch > (N + 1) / 2) nch = (N + 1) / 2;
+  if (nch < 1) nch = 1;
+  p.ic = (N + nch - 1) / nch;
+  p.nch = (N + p.ic - 1) / p.ic;
+  return p;
+}
+
 constexpr int C1_BLOCKS = 256;             // one persistent block per CU
 bool fast_c1(int N, int C, int Din, int Dout) { return C == 1 && N * Din == 4096 && Dout == 5; }
 
@@ -678,29 +907,69 @@ int launch_fwd(const cy_routing_fwd_t* a, hipStream_t s) {
   using T = WTile<DIN, DOUT>;
   constexpr int RW = (DOUT <= 16) ? 2 : 1;
   const size_t lds = (size_t)2 * a->C * T::WS * 4;
-  const int blocks = (a->R + 4 * RW - 1) / (4 * RW);
-  int rc = cy_allow_lds(routing_fwd_kernel<DIN, DOUT, RW>, lds);
+  const PhasePlan p = plan_phases(a->R, a->N, RW);
+  if (!p.phased) {
+    int rc = cy_allow_lds(routing_fwd_kernel<DIN, DOUT, RW>, lds);
+    if (rc) return rc;
+    routing_fwd_kernel<DIN, DOUT, RW><<<p.row_blocks, 256, lds, s>>>(*a);
+    return 0;
+  }
+  if (a->ws == nullptr) return cy_set_error(CY_EINVAL, "cy_routing_fwd: this shape needs the workspace (ws) of cy_routing_fwd_ws_floats()");
+  int rc = cy_allow_lds(routing_phase_kernel<DIN, DOUT, RW, 0>, lds);
   if (rc) return rc;
-  routing_fwd_kernel<DIN, DOUT, RW><<<blocks, 256, lds, s>>>(*a);
+  const long long plane = (long long)a->R * a->C * DOUT;
+  float* V = a->ws;
+  float* slab = a->ws + plane;
+  const int fin_blocks = (int)cy_ceil_div((long long)a->R * a->C, 128);
+  for (int it = 0; it < a->n_iter; ++it) {
+    PhaseArgs pa{a->u, a->W, it > 0 ? V : nullptr, nullptr, slab, a->R, a->N, a->C, it, p.ic, a->gather_g, a->gather_B};
+    routing_phase_kernel<DIN, DOUT, RW, 0><<<dim3(p.row_blocks, p.nch), 256, lds, s>>>(pa);
+    slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, a->s_hist + (long long)it * plane, p.nch, plane);
+    routing_fin_fwd_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(a->s_hist + (long long)it * plane, V, a->v_out, a->R, a->C, it,
+                                                            it == a->n_iter - 1, a->gather_g, a->gather_B);
+  }
   return 0;
 }
 template <int DIN, int DOUT>
 int launch_bwd(const cy_routing_bwd_t* a, hipStream_t s) {
   using T = WTile<DIN, DOUT>;
   const size_t lds1 = (size_t)2 * a->C * T::WS * 4;
-  int rc = cy_allow_lds(routing_bwd_rows_kernel<DIN, DOUT>, lds1);
-  if (rc) return rc;
-  routing_bwd_rows_kernel<DIN, DOUT><<<(a->R + 3) / 4, 256, lds1, s>>>(*a);
-  const int igroups = (a->N + 3) / 4;
+  const PhasePlan p = plan_phases(a->R, a->N, 1);
+  const long long plane = (long long)a->R * a->C * DOUT;
+  int rc;
+  if (!p.phased) {
+    rc = cy_allow_lds(routing_bwd_rows_kernel<DIN, DOUT>, lds1);
+    if (rc) return rc;
+    routing_bwd_rows_kernel<DIN, DOUT><<<(a->R + 3) / 4, 256, lds1, s>>>(*a);
+  } else {
+    float* ds_all = a->ws;
+    float* V_all = a->ws + (long long)a->n_iter * plane;
+    float* SA = a->ws + 2ll * a->n_iter * plane;
+    float* At = SA + plane;
+    float* slab = At + plane;
+    const int fin_blocks = (int)cy_ceil_div((long long)a->R * a->C, 128);
+    routing_bwd_prep_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(a->s_hist, a->dv, ds_all, V_all, SA, a->R, a->C, a->n_iter,
+                                                             a->gather_g, a->gather_B);
+    rc = cy_allow_lds(routing_phase_kernel<DIN, DOUT, 1, 1>, lds1);
+    if (rc) return rc;
+    for (int t = a->n_iter - 1; t >= 1; --t) {
+      PhaseArgs pa{a->u, a->W, V_all + (long long)t * plane, ds_all + (long long)t * plane, slab, a->R, a->N, a->C, t, p.ic,
+                   a->gather_g, a->gather_B};
+      routing_phase_kernel<DIN, DOUT, 1, 1><<<dim3(p.row_blocks, p.nch), 256, lds1, s>>>(pa);
+      slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, At, p.nch, plane);
+      routing_bwd_fin_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(At, a->s_hist, ds_all, SA, a->R, a->C, t);
+    }
+  }
+  const int igroups = (a->N + B2_WAVES - 1) / B2_WAVES;
   int chunks = (768 + igroups - 1) / igroups;
   if (chunks > (a->R + 15) / 16) chunks = (a->R + 15) / 16;
   if (chunks < 1) chunks = 1;
   const int rpc = (a->R + chunks - 1) / chunks;
   chunks = (a->R + rpc - 1) / rpc;
-  const size_t lds2 = (size_t)4 * a->C * T::WS * 4;
+  const size_t lds2 = (size_t)B2_WAVES * a->C * T::WS * 4;
   rc = cy_allow_lds(routing_bwd_caps_kernel<DIN, DOUT>, lds2);
   if (rc) return rc;
-  routing_bwd_caps_kernel<DIN, DOUT><<<dim3(igroups, chunks), 256, lds2, s>>>(*a, rpc);
+  routing_bwd_caps_kernel<DIN, DOUT><<<dim3(igroups, chunks), 64 * B2_WAVES, lds2, s>>>(*a, rpc);
   return 0;
 }
 
@@ -739,10 +1008,19 @@ extern "C" int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream) {
   return 0;
 }
 
+extern "C" long long cy_routing_fwd_ws_floats(const cy_routing_fwd_t* a) {
+  if (!a || fast_c1(a->N, a->C, a->Din, a->Dout)) return 0;
+  const PhasePlan p = plan_phases(a->R, a->N, a->Dout <= 16 ? 2 : 1);
+  if (!p.phased) return 0;
+  return (1ll + p.nch) * a->R * a->C * a->Dout;
+}
+
 extern "C" long long cy_routing_bwd_ws_floats(const cy_routing_bwd_t* a) {
   if (!a) return 0;
   if (fast_c1(a->N, a->C, a->Din, a->Dout)) return (long long)C1_BLOCKS * 4096 * 5;
-  return 2ll * a->n_iter * a->R * a->C * a->Dout;
+  const PhasePlan p = plan_phases(a->R, a->N, 1);
+  const long long plane = (long long)a->R * a->C * a->Dout;
+  return 2ll * a->n_iter * plane + (p.phased ? (2ll + p.nch) * plane : 0);
 }
 
 extern "C" int cy_routing_bwd(const cy_routing_bwd_t* a, void* stream) {

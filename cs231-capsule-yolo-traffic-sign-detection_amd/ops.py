@@ -274,7 +274,11 @@ class _Routing(torch.autograd.Function):
         v = _empty(out_shape, u)
         s_hist = _empty((n_iter, R, Cc, Dout), u)
         a = RoutingFwd(u=u.data_ptr(), W=W.data_ptr(), v_out=v.data_ptr(), s_hist=s_hist.data_ptr(), R=R, N=N, C=Cc,
-                       Din=Din, Dout=Dout, n_iter=n_iter, gather_g=gather_g, gather_B=gather_B)
+                       Din=Din, Dout=Dout, n_iter=n_iter, gather_g=gather_g, gather_B=gather_B, ws=None)
+        nws = query('cy_routing_fwd_ws_floats', C.byref(a))
+        if nws:
+            ws = _empty((nws,), u)
+            a.ws = ws.data_ptr()
         with timer.range('routing_fwd'):
             call('cy_routing_fwd', C.byref(a), _stream())
         ctx.save_for_backward(u, W, s_hist)

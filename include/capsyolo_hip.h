@@ -110,7 +110,11 @@ typedef struct {
   const float* u; const float* W; float* v_out; float* s_hist;
   int R, N, C, Din, Dout, n_iter;
   int gather_g, gather_B;
+  float* ws;            /* workspace of cy_routing_fwd_ws_floats() floats (0 for most shapes: may then be NULL) */
 } cy_routing_fwd_t;
+/* Few rows (R < ~1000) cannot fill the chip row-wise: the input capsules are then split over blocks too and each
+ * routing iteration becomes one phase launch + one finish launch (needs the workspace). */
+long long cy_routing_fwd_ws_floats(const cy_routing_fwd_t* a);
 int cy_routing_fwd(const cy_routing_fwd_t* a, void* stream);
 
 typedef struct {

@@ -142,7 +142,10 @@ def test_routing_golden(ci, n_iter):
 
 
 @pytest.mark.parametrize('shape', [(37, 70, 43, 8, 16, 3), (9, 33, 7, 8, 21, 2), (130, 512, 1, 8, 5, 3),
-                                   (5, 64, 64, 8, 16, 3), (3, 20, 3, 8, 5, 4)])
+                                   (5, 64, 64, 8, 16, 3), (3, 20, 3, 8, 5, 4),
+                                   # many rows: the single-launch fused kernels (few rows take the phased path)
+                                   (1100, 12, 5, 8, 16, 3), (600, 10, 7, 8, 21, 2), (1030, 9, 3, 8, 5, 3),
+                                   (32, 1296, 43, 8, 16, 3)])
 def test_routing_vs_oracle(shape):
     from capsyolo_amd import ops
     from oracle.models import dynamic_routing
