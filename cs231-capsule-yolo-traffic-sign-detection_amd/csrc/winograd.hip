@@ -1,0 +1,274 @@
+// Fused Winograd F(2x2, 3x3) convolution on the fp32 matrix cores (gfx950), for the 3x3 / stride 1 / pad 1
+// layers (DarkCapsuleNet conv_2 = 77 % of the model's FLOPs, models.py:351; its input gradient; DarkNet's 3x3s).
+//
+// fp32 MFMA runs at the vector rate (157 TFLOP/s) and the direct implicit GEMM already sits at ~80 % of it, so
+// the only way to be materially faster in exact fp32 is to do fewer multiplies:
+//   Y = A^T [ sum_ci (G g G^T) (.) (B^T d B) ] A      -- 16 multiplies per 2x2 outputs instead of 36 (2.25x).
+// Everything is fused in one kernel so that neither the transformed input (4x the activation) nor the 16
+// partial products ever touch HBM:
+//   block = 8x8 tiles (16x16 output pixels) x 64 output channels, 4 waves (2 x 2), ONE wave per SIMD with the
+//   whole 512-register file: each wave holds all 16 Winograd positions of its 32 tiles x 32 channels
+//   (16 accumulator tiles of mfma_f32_32x32x2f32 = 256 registers), so the output transform is lane-local.
+//   Per chunk of 8 input channels: raw 18x18 input patch -> LDS; every thread transforms part of a tile
+//   (B^T d B, adds only) into the 16 A images V[xi][k/4][tile][4]; the pre-transformed weights U[xi][k/4][co][4]
+//   are copied to LDS; each wave then issues 16 positions x 4 MFMAs.  The transform of chunk c+1 and the
+//   global loads of chunk c+2 are issued between the MFMAs of chunk c (three-stage software pipeline, two
+//   barriers per chunk).
+#include "common.h"
+
+namespace {
+
+constexpr int WT = 64;                      // tiles per block (8 x 8)
+constexpr int WN = 64;                      // output channels per block
+constexpr int KC = 8;                       // input channels per chunk
+constexpr int SLAB = WT * 4 + 4;            // floats per (xi, kq) slab of V or U (16 B pad)
+constexpr int VU_BUF = 32 * SLAB;           // 16 positions x 2 k-quads
+constexpr int RAWP = 328;                   // 18*18 = 324 pixels, padded
+constexpr int RAW_BUF = 2 * RAWP * 4;       // [kq][pixel][4]
+
+struct WinoArgs {
+  const float* X; const float* U; float* Y; const float* bias; double* stats;
+  int B, H, W, Cin, Cout, Np, tbh, tbw;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                         // [2][VU_BUF]
+  float* Us = smem + 2 * VU_BUF;            // [2][VU_BUF]
+  float* Rs = smem + 4 * VU_BUF;            // [2][RAW_BUF]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  const int nblk = a.Np / WN;
+  const int nb = blockIdx.x % nblk;
+  int rest = blockIdx.x / nblk;
+  const int tbx = rest % a.tbw; rest /= a.tbw;
+  const int tby = rest % a.tbh;
+  const int b = rest / a.tbh;
+  const int oy0 = tby * 16, ox0 = tbx * 16;
+
+  // ---- per-thread constants of the loaders
+  // raw patch: item = pixel*2 + kq (32 B contiguous per pixel), 648 items over 256 threads
+  long long goff[3]; bool gok[3]; int roff[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int item = t + 256 * q;
+    const int pix = item >> 1, kq = item & 1;
+    const int py = pix / 18, px = pix - py * 18;
+    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+    gok[q] = item < 648 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    goff[q] = (((long long)b * a.H + iy) * a.W + ix) * a.Cin + kq * 4;
+    roff[q] = item < 648 ? (kq * RAWP + pix) * 4 : -1;
+  }
+  // U chunk: 32 segments (xi*2+kq) of 64 channels x float4; thread -> float4 f = t + 256q
+  const float* usrc = a.U + ((long long)(t >> 6) * a.Np + nb * WN + (t & 63)) * 4;   // segment t>>6 (+4 per q)
+  const long long useg = (long long)4 * a.Np * 4;      // 4 segments further per q
+  const long long uchunk = (long long)32 * a.Np * 4;
+  const int uoff = (t >> 6) * SLAB + (t & 63) * 4;     // + 4*SLAB per q
+  // transform item: tile = t & 63, kq = (t >> 6) & 1, rh = t >> 7 (rows 2rh, 2rh+1 of V)
+  const int ttile = t & 63, tkq = (t >> 6) & 1, trh = t >> 7;
+  const int tbase = (tkq * RAWP + (2 * (ttile >> 3) + trh) * 18 + 2 * (ttile & 7)) * 4;   // row `trh` of the 4x4 patch
+  const int vdst = ((2 * trh) * 4 * 2 + tkq) * SLAB + ttile * 4;                          // xi = (2rh)*4 + c -> + c*2*SLAB
+
+  f32x4 graw[3], gu[8];
+  const int nchunk = a.Cin / KC;
+
+  auto G = [&](int c) {                     // global -> registers
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gok[q]) v = *(const f32x4*)(a.X + (goff[q] + (long long)c * KC));
+      graw[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) gu[q] = *(const f32x4*)(usrc + (long long)c * uchunk + q * useg);
+  };
+  auto S = [&](int c) {                     // registers -> LDS (raw patch, U)
+    float* rb = Rs + (c & 1) * RAW_BUF;
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+      if (roff[q] >= 0) *(f32x4*)(rb + roff[q]) = graw[q];
+    float* ub = Us + (c & 1) * VU_BUF;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) *(f32x4*)(ub + uoff + q * 4 * SLAB) = gu[q];
+  };
+  auto T = [&](int c) {                     // raw patch -> two rows of V = B^T d B (this thread's tile, 4 channels)
+    const float* rb = Rs + (c & 1) * RAW_BUF + tbase;
+    f32x4 x0[4], x1[4], x2[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      x0[cc] = *(const f32x4*)(rb + cc * 4);
+      x1[cc] = *(const f32x4*)(rb + (18 + cc) * 4);
+      x2[cc] = *(const f32x4*)(rb + (36 + cc) * 4);
+    }
+    // rows of B^T d:  rh=0: (d0 - d2, d1 + d2) from rows (0,1,2);  rh=1: (d2 - d1, d1 - d3) from rows (1,2,3)
+    f32x4 tA[4], tB[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc) {
+      tA[cc] = trh ? (x1[cc] - x0[cc]) : (x0[cc] - x2[cc]);
+      tB[cc] = trh ? (x0[cc] - x2[cc]) : (x1[cc] + x2[cc]);
+    }
+    float* vb = Vs + (c & 1) * VU_BUF + vdst;
+    // columns of (.) B:  (t0 - t2, t1 + t2, t2 - t1, t1 - t3)
+    *(f32x4*)(vb + 0 * 2 * SLAB) = tA[0] - tA[2];
+    *(f32x4*)(vb + 1 * 2 * SLAB) = tA[1] + tA[2];
+    *(f32x4*)(vb + 2 * 2 * SLAB) = tA[2] - tA[1];
+    *(f32x4*)(vb + 3 * 2 * SLAB) = tA[1] - tA[3];
+    *(f32x4*)(vb + 4 * 2 * SLAB) = tB[0] - tB[2];
+    *(f32x4*)(vb + 5 * 2 * SLAB) = tB[1] + tB[2];
+    *(f32x4*)(vb + 6 * 2 * SLAB) = tB[2] - tB[1];
+    *(f32x4*)(vb + 7 * 2 * SLAB) = tB[1] - tB[3];
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+  // ---- prologue: chunk 0 fully staged and transformed, chunk 1 staged
+  G(0);
+  S(0);
+  if (nchunk > 1) G(1);
+  __syncthreads();
+  T(0);
+  if (nchunk > 1) S(1);
+  __syncthreads();
+
+  const int fragA = lh * SLAB + (wm * 32 + li) * 4;
+  const int fragB = lh * SLAB + (wn * 32 + li) * 4;
+  for (int c = 0; c < nchunk; ++c) {
+    if (c + 2 < nchunk) G(c + 2);
+    const float* vb = Vs + (c & 1) * VU_BUF + fragA;
+    const float* ub = Us + (c & 1) * VU_BUF + fragB;
+    // M(c): 16 positions x 4 MFMAs, with T(c+1) spread between them by the scheduler
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) {
+      const f32x4 fa = *(const f32x4*)(vb + xi * 2 * SLAB);
+      const f32x4 fb = *(const f32x4*)(ub + xi * 2 * SLAB);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[xi] = mfma32(fa[e], fb[e], acc[xi]);
+    }
+    if (c + 1 < nchunk) T(c + 1);
+    __syncthreads();
+    if (c + 2 < nchunk) S(c + 2);
+    __syncthreads();
+  }
+
+  // ---- output transform (lane-local): Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+  const int co = nb * WN + wn * 32 + li;
+  const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int oy = oy0 + 2 * (tl >> 3), ox = ox0 + 2 * (tl & 7);
+    float s0[4], s1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+      s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+    }
+    const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+    const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+    if (co < a.Cout && oy < a.H && ox < a.W) {
+      float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + co;
+      yp[0] = y00; ssum += y00; ssq += y00 * y00;
+      if (ox + 1 < a.W) { yp[a.Cout] = y01; ssum += y01; ssq += y01 * y01; }
+      if (oy + 1 < a.H) {
+        yp[(long long)a.W * a.Cout] = y10; ssum += y10; ssq += y10 * y10;
+        if (ox + 1 < a.W) { yp[(long long)a.W * a.Cout + a.Cout] = y11; ssum += y11; ssq += y11 * y11; }
+      }
+    }
+  }
+  if (a.stats != nullptr) {
+    float* red = smem;                      // [2 wm][WN][2]; all LDS readers are past the loop's last barrier
+    ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (lh == 0) {
+      red[(wm * WN + wn * 32 + li) * 2 + 0] = ssum;
+      red[(wm * WN + wn * 32 + li) * 2 + 1] = ssq;
+    }
+    __syncthreads();
+    if (t < WN && nb * WN + t < a.Cout) {
+      atomicAdd(a.stats + 2 * (nb * WN + t), (double)red[t * 2] + (double)red[(WN + t) * 2]);
+      atomicAdd(a.stats + 2 * (nb * WN + t) + 1, (double)red[t * 2 + 1] + (double)red[(WN + t) * 2 + 1]);
+    }
+  }
+}
+
+// U[chunk][xi][kq][co (Np)][e] = (G g G^T)[xi] for ci = chunk*8 + kq*4 + e.
+// transpose = 0: g = W[co][ci][.][.] (forward);  1: input gradient, g[kh][kw] = W[ci][co][2-kh][2-kw]
+__global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout_l, int Cin_l, int transpose,
+                                 int Cin, int Np, int Ncols, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx & 3);
+  long long r = idx >> 2;
+  const int co = (int)(r % Np); r /= Np;
+  const int kq = (int)(r & 1); r >>= 1;
+  const int xi = (int)(r & 15); r >>= 4;
+  const int ci = (int)r * 8 + kq * 4 + e;
+  float u = 0.f;
+  if (ci < Cin && co < Ncols) {
+    float g[3][3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw)
+        g[kh][kw] = transpose ? W[(((long long)ci * Cin_l + co) * 3 + (2 - kh)) * 3 + (2 - kw)]
+                              : W[(((long long)co * Cin_l + ci) * 3 + kh) * 3 + kw];
+    (void)Cout_l;
+    const float Gm[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    const int i = xi >> 2, j = xi & 3;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) u += Gm[i][p] * g[p][q] * Gm[j][q];
+  }
+  U[idx] = u;
+}
+
+}  // namespace
+
+extern "C" long long cy_wino_packed_floats(int Cin, int N) {
+  return (long long)((Cin + 7) / 8) * 16 * 2 * ((N + 63) / 64 * 64) * 4;
+}
+
+extern "C" int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream) {
+  CY_REQUIRE(W && U && Cout > 0 && Cin > 0, "cy_wino_pack_weights: bad arguments");
+  const int cin_g = transpose ? Cout : Cin, n_g = transpose ? Cin : Cout;
+  const int Np = (n_g + 63) / 64 * 64;
+  const long long total = cy_wino_packed_floats(cin_g, n_g);
+  wino_pack_kernel<<<(unsigned)cy_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(W, U, Cout, Cin, transpose, cin_g, Np,
+                                                                                       n_g, total);
+  CY_LAUNCH_CHECK("cy_wino_pack_weights");
+  return 0;
+}
+
+extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, int B, int H,
+                                   int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv3x3_winograd: bad arguments");
+  CY_REQUIRE(Cin % KC == 0 && Cin >= KC, "cy_conv3x3_winograd: Cin=%d must be a multiple of %d", Cin, KC);
+  CY_REQUIRE((((uintptr_t)X | (uintptr_t)U) & 15) == 0, "cy_conv3x3_winograd: operands must be 16-byte aligned");
+  WinoArgs a;
+  a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.Np = (Cout + 63) / 64 * 64;
+  a.tbh = (H + 15) / 16; a.tbw = (W + 15) / 16;
+  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / WN);
+  CY_REQUIRE(blocks < (1ll << 31), "cy_conv3x3_winograd: grid too large");
+  const size_t lds = (size_t)(4 * VU_BUF + 2 * RAW_BUF) * 4;
+  int rc = cy_allow_lds(wino_conv_kernel, lds);
+  if (rc) return rc;
+  wino_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  CY_LAUNCH_CHECK("cy_conv3x3_winograd");
+  return 0;
+}

@@ -78,12 +78,35 @@ def _x_geometry(x, nchw):
     return B, Hi, Wi, Cin, (Hi * Wi * Cin, Wi * Cin, Cin, 1)
 
 
+USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
+
+
+def _winograd_ok(k, stride, pad, cin, nchw):
+    return USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and not nchw and cin % 8 == 0 and cin >= 8
+
+
+def _winograd(x, weight, bias, stats, transpose, tag):
+    """x [B,H,W,Cg] NHWC; weight in PyTorch layout; transpose=True computes the input gradient of the layer."""
+    B, H, W_, Cg = x.shape
+    Cout_l, Cin_l = weight.shape[0], weight.shape[1]
+    n = Cin_l if transpose else Cout_l
+    st = _stream()
+    u = _empty((query('cy_wino_packed_floats', Cg, n),), x)
+    call('cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
+    y = _empty((B, H, W_, n), x)
+    with timer.range(('conv_wino_dgrad/' if transpose else 'conv_wino_fwd/') + tag):
+        call('cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), B, H, W_, Cg, n, st)
+    return y
+
+
 def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv'):
     """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
     x, weight = _f32(x, 'conv input'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     Cout = weight.shape[0]
     Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    if not relu and _winograd_ok(k, stride, pad, Cin, nchw):
+        return _winograd(x, weight, bias, stats, False, tag)
     st = _stream()
     wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
     call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, k, k, 0, 0, 1, 0, st)
@@ -129,6 +152,8 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
     dz, weight = _f32(dz, 'grad'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin = in_shape
     _, Ho, Wo, Cout = dz.shape
+    if _winograd_ok(k, stride, pad, Cout, False):
+        return _winograd(dz, weight, None, None, True, tag)
     st = _stream()
     dx = _empty((B, Hi, Wi, Cin), dz)
     wp = _empty((query('cy_conv_packed_floats', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dz)

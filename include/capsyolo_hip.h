@@ -71,6 +71,15 @@ typedef struct {
 long long cy_conv_wgrad_ws_floats(const cy_conv_wgrad_t* a);
 int cy_conv_wgrad(const cy_conv_wgrad_t* a, void* stream);
 
+/* Fused Winograd F(2x2,3x3) for 3x3 / stride 1 / pad 1 convolutions on NHWC (2.25x fewer multiplies than the
+ * implicit GEMM; fp32 error ~1e-6 relative).  U = cy_wino_pack_weights(W[Cout][Cin][3][3]); transpose=1 packs
+ * the input-gradient operand (then call with X = dZ, Cin = layer Cout, Cout = layer Cin).  Cin % 8 == 0.
+ * bias / stats as in cy_conv_gemm (either may be NULL). */
+long long cy_wino_packed_floats(int Cin, int N);
+int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
+int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
+                        int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */
 int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream);
 

@@ -65,6 +65,39 @@ def test_conv_fwd_dgrad_wgrad(case):
         close(dx.permute(0, 3, 1, 2), xd.grad, 5e-5, 5e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10)])
+def test_conv3x3_winograd_matches_direct_and_fp64(case):
+    """Fused Winograd F(2x2,3x3) (forward + input gradient, bias, BN statistics, odd sizes, padded channels)
+    against torch fp64, and switched off against the direct implicit GEMM."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    x = rnd((B, Cin, H, H), 61)
+    w = rnd((Cout, Cin, 3, 3), 62, (1.0 / (Cin * 9)) ** 0.5)
+    b = rnd((Cout,), 63, 0.1)
+    xd, wd = x.double().requires_grad_(True), w.double()
+    zr = F.conv2d(xd, wd, b.double(), padding=1)
+    gz = rnd(tuple(zr.shape), 64)
+    zr.backward(gz.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    assert ops.USE_WINOGRAD
+    stats = torch.zeros((Cout, 2), dtype=torch.float64, device=dev())
+    z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1, False, stats)
+    dx = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), 3, 1, 1)
+    close(z.permute(0, 3, 1, 2), zr, 5e-5, 5e-5)
+    close(dx.permute(0, 3, 1, 2), xd.grad, 1e-4, 1e-4)
+    close(stats[:, 0], zr.sum(dim=(0, 2, 3)), 1e-4, 1e-4)
+    close(stats[:, 1], (zr ** 2).sum(dim=(0, 2, 3)), 1e-4, 1e-4)
+    try:
+        ops.USE_WINOGRAD = False
+        z2 = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1)
+        dx2 = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), 3, 1, 1)
+    finally:
+        ops.USE_WINOGRAD = True
+    close(z, z2, 1e-4, 1e-4)
+    close(dx, dx2, 2e-4, 2e-4)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
