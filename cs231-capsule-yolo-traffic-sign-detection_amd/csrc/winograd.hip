@@ -35,6 +35,53 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- compile-time schedule of one chunk (64 slots = 64 MFMAs per wave)
+// Slot s issues the MFMA of position xi(s), k-step e(s); positions are interleaved in pairs so that consecutive
+// MFMAs never share an accumulator:  (x0,e0) (x1,e0) (x0,e1) (x1,e1) ... (x0,e3) (x1,e3) (x2,e0) ...
+constexpr int wino_xi(int s) { return (s & 1) + 2 * (s >> 3); }
+constexpr int wino_e(int s) { return (s >> 1) & 3; }
+// the fragments of position xi are fetched right after the MFMA of slot wino_issue(xi) and first used in slot wino_use(xi)
+constexpr int wino_use(int xi) { return 8 * (xi >> 1) + (xi & 1); }
+constexpr int wino_issue(int xi) { return wino_use(xi) - 8; }              // < 0: fetched before the loop body
+constexpr int wino_frag_pos(int s) { return ((s & 7) < 2 && s + 8 < 64) ? wino_xi(s) + 2 : -1; }   // position prefetched in slot s
+// side work, one piece per slot (see the slot body):
+//   1 S_U   U(c+1) registers -> LDS (2 pieces)      2 G_raw  patch loads of chunk c+2 (3)     3 G_U  U loads of c+2 (8)
+//   4 T_rd  patch rows of chunk c+1 from LDS (3)     5 T_bt   rows of B^T d (8)                6 T_v  V positions (8)
+//   7 S_raw patch of chunk c+2 registers -> LDS (3)
+constexpr int wino_side_kind(int s) {
+  if (s < 2) return 1;
+  if (s < 5) return 2;
+  if (s < 13) return 3;
+  if (s < 16) return 4;
+  if (s >= 17 && s < 25) return 5;
+  if (s >= 26 && s < 34) return 6;
+  if (s >= 44 && s < 47) return 7;
+  return 0;
+}
+constexpr int wino_side_idx(int s) {
+  return s < 2 ? s : s < 5 ? s - 2 : s < 13 ? s - 5 : s < 16 ? s - 13 : s < 25 ? s - 17 : s < 34 ? s - 26 : s - 44;
+}
+constexpr int wino_side_lds(int s) {
+  const int k = wino_side_kind(s);
+  // a LOWER bound of the LDS instructions the slot issues (the waits below may never allow more outstanding
+  // operations than are really younger): the S_raw store is exec-masked and may be skipped by a whole wave
+  return (k == 1 || k == 4) ? 4 : (k == 6) ? 1 : 0;
+}
+constexpr int wino_frag_lds(int s) { return wino_frag_pos(s) >= 0 ? 2 : 0; }
+// LDS operations younger than position xi's fragments when its first MFMA issues (s_waitcnt lgkmcnt operand)
+constexpr int wino_younger(int xi) {
+  const int is = wino_issue(xi), us = wino_use(xi);
+  int n = 0;
+  if (is < 0) {                            // prologue order: frags of x0, then x1
+    if (xi == 0) n += 2;                   // x1's fragments are younger than x0's
+    for (int s = 0; s < us; ++s) n += wino_frag_lds(s) + wino_side_lds(s);
+  } else {
+    n += wino_side_lds(is);
+    for (int s = is + 1; s < us; ++s) n += wino_frag_lds(s) + wino_side_lds(s);
+  }
+  return n > 15 ? 15 : n;
+}
+
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][VU_BUF]
@@ -80,24 +127,29 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   f32x4 graw[3], gu[8];
   const int nchunk = a.Cin / KC;
 
-  auto G = [&](int c) {                     // global -> registers
+  // global -> registers (unconditional loads: out-of-image pixels read a valid address and are zeroed, so the
+  // chunk body stays straight-line code and hipcc's vmcnt counts stay exact)
+  auto Graw = [&](int c, f32x4 (&dst)[3]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (gok[q]) v = *(const f32x4*)(a.X + (goff[q] + (long long)c * KC));
-      graw[q] = v;
+      const f32x4 v = *(const f32x4*)(a.X + ((gok[q] ? goff[q] : 0ll) + (long long)c * KC));
+      dst[q] = gok[q] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) gu[q] = *(const f32x4*)(usrc + (long long)c * uchunk + q * useg);
   };
-  auto S = [&](int c) {                     // registers -> LDS (raw patch, U)
+  auto GU = [&](int c, f32x4 (&dst)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) dst[q] = *(const f32x4*)(usrc + (long long)c * uchunk + q * useg);
+  };
+  auto Sraw = [&](int c, const f32x4 (&src)[3]) {   // registers -> LDS raw patch buffer c & 1
     float* rb = Rs + (c & 1) * RAW_BUF;
 #pragma unroll
     for (int q = 0; q < 3; ++q)
-      if (roff[q] >= 0) *(f32x4*)(rb + roff[q]) = graw[q];
+      if (roff[q] >= 0) *(f32x4*)(rb + roff[q]) = src[q];
+  };
+  auto SU = [&](int c, const f32x4 (&src)[8]) {     // registers -> LDS U buffer c & 1
     float* ub = Us + (c & 1) * VU_BUF;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) *(f32x4*)(ub + uoff + q * 4 * SLAB) = gu[q];
+    for (int q = 0; q < 8; ++q) *(f32x4*)(ub + uoff + q * 4 * SLAB) = src[q];
   };
   auto T = [&](int c) {                     // raw patch -> two rows of V = B^T d B (this thread's tile, 4 channels)
     const float* rb = Rs + (c & 1) * RAW_BUF + tbase;
@@ -133,42 +185,109 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
 
-  // ---- prologue: chunk 0 fully staged and transformed, chunk 1 staged
-  G(0);
-  S(0);
-  if (nchunk > 1) G(1);
-  __syncthreads();
-  T(0);
-  if (nchunk > 1) S(1);
-  __syncthreads();
-
+  // ---- prologue.  Pipeline state at the top of chunk c: V[c&1] = transformed chunk c, U[c&1] = weights of chunk c,
+  // raw[(c+1)&1] = input patch of chunk c+1, registers gu = weights of chunk c+1.  Both chunks' global loads are
+  // issued back to back so that the block pays one memory round trip.
+  {
+    f32x4 graw1[3];
+    const int c1 = nchunk > 1 ? 1 : 0;
+    Graw(0, graw);
+    GU(0, gu);
+    Graw(c1, graw1);
+    Sraw(0, graw);
+    SU(0, gu);
+    GU(c1, gu);
+    __syncthreads();
+    T(0);
+    Sraw(1, graw1);
+    __syncthreads();
+  }
   const int fragA = lh * SLAB + (wm * 32 + li) * 4;
-  const int fragB = lh * SLAB + (wn * 32 + li) * 4;
+  const int fragB = lh * SLAB + (wm * 0 + wn * 32 + li) * 4;
+  // One chunk = 64 MFMAs per wave.  There is ONE wave per SIMD, and a wave issues in order: while it waits to
+  // issue the next MFMA (the pipe is busy for 64 cycles) nothing behind that MFMA can issue.  So every other
+  // piece of work of the pipeline -- fragment reads for the next position, the input transform of chunk c+1
+  // (LDS reads, adds, LDS writes) and the global loads of chunk c+2 -- is cut into ~40 small pieces and ONE
+  // piece is placed after each MFMA in program order (pinned with sched_barrier), where it executes in that
+  // MFMA's shadow.  LDS operations complete in order, so the fragments of position xi+1 (read right after
+  // position xi's first MFMA) are ready when `lgkmcnt(0)` is checked three MFMAs later.
   for (int c = 0; c < nchunk; ++c) {
-    if (c + 2 < nchunk) G(c + 2);
-    const float* vb = Vs + (c & 1) * VU_BUF + fragA;
-    const float* ub = Us + (c & 1) * VU_BUF + fragB;
-    // M(c): 16 positions x 4 MFMAs, with T(c+1) spread between them by the scheduler
-#pragma unroll
-    for (int xi = 0; xi < 16; ++xi) {
-      const f32x4 fa = *(const f32x4*)(vb + xi * 2 * SLAB);
-      const f32x4 fb = *(const f32x4*)(ub + xi * 2 * SLAB);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) acc[xi] = mfma32(fa[e], fb[e], acc[xi]);
+    const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
+    const float* ub_ = Us + (c & 1) * VU_BUF + fragB;
+    const float* rb_ = Rs + ((c + 1) & 1) * RAW_BUF + tbase;        // T(c+1) reads ...
+    float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last chunk)
+    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G(c+2), clamped: the last chunks re-load valid data
+    const long long gx = (long long)cg * KC;
+    const float* gusrc = usrc + (long long)cg * uchunk;
+    float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(c+1) (harmless after the last chunk)
+    float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(c+2) -> raw[(c+2)&1]
+    f32x4 x0_[4], x1_[4], x2_[4], tA_[4], tB_[4];
+    f32x4 fa_[4], fb_[4];                   // fragment sets, indexed by position & 3
+    fa_[0] = *(const f32x4*)(vb_);
+    fb_[0] = *(const f32x4*)(ub_);
+    fa_[1] = *(const f32x4*)(vb_ + 2 * SLAB);
+    fb_[1] = *(const f32x4*)(ub_ + 2 * SLAB);
+#define WSLOT(SIDX)                                                                                 \
+    {                                                                                               \
+      constexpr int sidx = (SIDX);                                                                  \
+      constexpr int xi = wino_xi(sidx), e = wino_e(sidx);                                           \
+      if (e == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (wino_younger(xi) << 8));                     \
+      acc[xi] = mfma32(fa_[xi & 3][e], fb_[xi & 3][e], acc[xi]);                                    \
+      constexpr int fp = wino_frag_pos(sidx);                                                       \
+      if (fp >= 0) {                                                                                \
+        constexpr int fq = fp >= 0 ? fp : 0;                                                        \
+        fa_[fq & 3] = *(const f32x4*)(vb_ + fq * 2 * SLAB);                                         \
+        fb_[fq & 3] = *(const f32x4*)(ub_ + fq * 2 * SLAB);                                         \
+      }                                                                                             \
+      constexpr int kind = wino_side_kind(sidx), k_ = wino_side_idx(sidx);                          \
+      if (kind == 1) {                      /* U(c+1): registers -> LDS, 4 float4 per piece */     \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
+          *(f32x4*)(uw_ + (k_ * 4 + q) * 4 * SLAB) = gu[k_ * 4 + q];                                \
+      } else if (kind == 2) {               /* patch loads of chunk c+2 */                         \
+        const f32x4 v_ = *(const f32x4*)(a.X + ((gok[k_] ? goff[k_] : 0ll) + gx));                  \
+        graw[k_] = gok[k_] ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                        \
+      } else if (kind == 3) {               /* weight loads of chunk c+2 */                        \
+        gu[k_] = *(const f32x4*)(gusrc + k_ * useg);                                                \
+      } else if (kind == 4) {               /* patch rows of chunk c+1 */                          \
+        if (k_ == 0) { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x0_[cc] = *(const f32x4*)(rb_ + cc * 4); } \
+        else if (k_ == 1) { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x1_[cc] = *(const f32x4*)(rb_ + (18 + cc) * 4); } \
+        else { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x2_[cc] = *(const f32x4*)(rb_ + (36 + cc) * 4); } \
+      } else if (kind == 5) {               /* rows of B^T d: patch column k_>>1 */                 \
+        constexpr int cc = k_ >> 1;                                                                 \
+        if ((k_ & 1) == 0) tA_[cc] = trh ? (x1_[cc] - x0_[cc]) : (x0_[cc] - x2_[cc]);               \
+        else tB_[cc] = trh ? (x0_[cc] - x2_[cc]) : (x1_[cc] + x2_[cc]);                             \
+      } else if (kind == 6) {               /* columns of (.) B: one V position per slot */         \
+        const f32x4* tt_ = (k_ < 4) ? tA_ : tB_;                                                    \
+        constexpr int cj_ = k_ & 3;                                                                 \
+        const f32x4 v_ = cj_ == 0 ? (tt_[0] - tt_[2]) : cj_ == 1 ? (tt_[1] + tt_[2])                \
+                       : cj_ == 2 ? (tt_[2] - tt_[1]) : (tt_[1] - tt_[3]);                          \
+        *(f32x4*)(vw_ + k_ * 2 * SLAB) = v_;                                                        \
+      } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
+        if (roff[k_] >= 0) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                    \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
     }
-    if (c + 1 < nchunk) T(c + 1);
-    __syncthreads();
-    if (c + 2 < nchunk) S(c + 2);
-    __syncthreads();
+#define WSLOT4(B) WSLOT((B)) WSLOT((B) + 1) WSLOT((B) + 2) WSLOT((B) + 3)
+#define WSLOT16(B) WSLOT4((B)) WSLOT4((B) + 4) WSLOT4((B) + 8) WSLOT4((B) + 12)
+    WSLOT16(0) WSLOT16(16) WSLOT16(32) WSLOT16(48)
+#undef WSLOT16
+#undef WSLOT4
+#undef WSLOT
+    __syncthreads();                        // the only barrier of the chunk
   }
 
   // ---- output transform (lane-local): Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+  // The wave's 32 tiles x 32 channels (128 pixels) go through its private 16 KiB of LDS so that the global
+  // stores are 16 bytes per lane (8 lanes per pixel): 16 store instructions per lane instead of 64 -- the
+  // store tail of a one-block-per-CU kernel is issue-bound and nothing overlaps it.
   const int co = nb * WN + wn * 32 + li;
   const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
   float ssum = 0.f, ssq = 0.f;
+  float* ow = smem + wave * 4096;           // [pixel = tile*4 + 2a + b][32 channels]
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int tl = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+    const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;       // tile within the wave's 32
+    const int tl = wm * 32 + tloc;
     const int oy = oy0 + 2 * (tl >> 3), ox = ox0 + 2 * (tl & 7);
     float s0[4], s1[4];
 #pragma unroll
@@ -178,16 +297,38 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     }
     const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
     const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
-    if (co < a.Cout && oy < a.H && ox < a.W) {
-      float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + co;
-      yp[0] = y00; ssum += y00; ssq += y00 * y00;
-      if (ox + 1 < a.W) { yp[a.Cout] = y01; ssum += y01; ssq += y01 * y01; }
-      if (oy + 1 < a.H) {
-        yp[(long long)a.W * a.Cout] = y10; ssum += y10; ssq += y10 * y10;
-        if (ox + 1 < a.W) { yp[(long long)a.W * a.Cout + a.Cout] = y11; ssum += y11; ssq += y11 * y11; }
+    float* op = ow + tloc * 128 + li;
+    op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
+    if (co < a.Cout && oy < a.H && ox < a.W) {              // statistics over the outputs that exist
+      const bool vx = ox + 1 < a.W, vy = oy + 1 < a.H;
+      ssum += y00; ssq += y00 * y00;
+      if (vx) { ssum += y01; ssq += y01 * y01; }
+      if (vy) { ssum += y10; ssq += y10 * y10; }
+      if (vx && vy) { ssum += y11; ssq += y11 * y11; }
+    }
+  }
+  {
+    const int c4 = lane & 7;
+    const int cbase = nb * WN + wn * 32 + c4 * 4;
+    const bool vec_ok = (a.Cout & 3) == 0;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int p = it * 8 + (lane >> 3);                   // pixel of the wave: tile*4 + 2a + b
+      const int tloc = p >> 2, ab = p & 3;
+      const int tl = wm * 32 + tloc;
+      const int oy = oy0 + 2 * (tl >> 3) + (ab >> 1), ox = ox0 + 2 * (tl & 7) + (ab & 1);
+      const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
+      if (oy < a.H && ox < a.W) {
+        float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + cbase;
+        if (vec_ok && cbase + 3 < a.Cout) *(f32x4*)yp = v;
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (cbase + k < a.Cout) yp[k] = v[k];
+        }
       }
     }
   }
+  __syncthreads();                          // the statistics reduction below reuses the LDS
   if (a.stats != nullptr) {
     float* red = smem;                      // [2 wm][WN][2]; all LDS readers are past the loop's last barrier
     ssum += __shfl_xor(ssum, 32, 64);
