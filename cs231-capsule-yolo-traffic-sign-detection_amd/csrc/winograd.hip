@@ -377,6 +377,331 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
   U[idx] = u;
 }
 
+// ================================================================================================ weight gradient
+// dW (3x3) through Winograd F(3x3, 2x2): per 2x2-output tile, dW_tile = A^T [ (G dY G^T) (.) (B^T d B) ] A with
+//   B^T = [[1,0,-1,0],[0,1,1,0],[0,-1,1,0],[0,-1,0,1]],  G = [[1,0],[.5,.5],[.5,-.5],[0,1]],  A^T = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]
+// The sum over tiles and images commutes with the output transform, so the heavy part is 16 GEMMs
+//   dU_xi[ci][co] = sum_tiles V_xi[tile][ci] * Z_xi[tile][co]        (2.25x fewer multiplies than the direct form)
+// with the reduction (tiles) as the MFMA k dimension.  One block = 64 ci x 64 co of ONE image (the per-image
+// partial sums are added by the finish kernel, which also applies A^T . A); 4 waves (2 x 2), one per SIMD, 16
+// accumulator tiles each, same slot-scheduled pipeline as the forward kernel.  A chunk is 8 tiles (2 x 4):
+// its 6x10 input patch and 4x8 dY patch are staged raw in LDS (256-byte rows, fully coalesced), every thread
+// transforms two tiles of one channel of each operand into the [xi][k/4][channel][4 tiles] images.
+constexpr int GT = 8;                       // tiles per chunk (2 rows x 4 columns of tiles)
+constexpr int XP = 60, ZP = 32;             // raw patch pixels: 6x10 input, 4x8 dY
+constexpr int XPS = 64;                     // input patch rows allocated (4 spare: every thread stores 4 float4)
+constexpr int RAWW_BUF = (XPS + ZP) * 64;   // floats: [pixel][64 channels] for both operands (single buffer)
+
+struct WinoWgradArgs {
+  const float* X; const float* dZ; float* slab;
+  int B, H, W, Cin, Cout, gh, gw;           // gh x gw tile groups per image
+};
+
+constexpr int wg_side_kind(int s) {         // one piece of side work per MFMA slot
+  // 1 G (6 global loads)  2 T_x reads (3 x 8)  3 T_z reads (1 x 8)  4 V transform+writes (4 pieces)
+  // 5 Z transform+writes (2 pieces)  6 mid barrier  7 S_raw (6 LDS writes, 2 per piece)
+  if (s >= 2 && s < 8) return 1;
+  if (s >= 9 && s < 12) return 2;
+  if (s == 13) return 3;
+  if (s >= 17 && s < 21) return 4;
+  if (s >= 22 && s < 24) return 5;
+  if (s == 40) return 6;
+  if (s >= 44 && s < 47) return 7;
+  return 0;
+}
+constexpr int wg_side_idx(int s) {
+  return s < 8 ? s - 2 : s < 12 ? s - 9 : s == 13 ? 0 : s < 21 ? s - 17 : s < 24 ? s - 22 : s < 44 ? 0 : s - 44;
+}
+constexpr int wg_side_lds(int s) {          // lower bound of the LDS instructions issued by the slot
+  const int k = wg_side_kind(s);
+  // (b32 patch reads pair up into ds_read2st64_b32: 8 reads = 4 instructions)
+  return k == 2 ? 4 : k == 3 ? 4 : k == 4 ? 4 : k == 5 ? 8 : k == 7 ? 2 : 0;
+}
+constexpr int wg_younger(int xi) {
+  const int is = wino_issue(xi), us = wino_use(xi);
+  int n = 0;
+  if (is < 0) {
+    if (xi == 0) n += 2;
+    for (int s = 0; s < us; ++s) n += wino_frag_lds(s) + wg_side_lds(s);
+  } else {
+    n += wg_side_lds(is);
+    for (int s = is + 1; s < us; ++s) n += wino_frag_lds(s) + wg_side_lds(s);
+  }
+  return n > 15 ? 15 : n;
+}
+
+__global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                         // [2][VU_BUF]   A images (input, rows = ci)
+  float* Zs = smem + 2 * VU_BUF;            // [2][VU_BUF]   B images (dY, rows = co)
+  float* Rw = smem + 4 * VU_BUF;            // [XP + ZP][64] raw patches
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ncb = a.Cout / 64, nib = a.Cin / 64;
+  const int cob = blockIdx.x % ncb;
+  const int cib = (blockIdx.x / ncb) % nib;
+  const int b = blockIdx.x / (ncb * nib);
+  const int nchunk = a.gh * a.gw;
+
+  // ---- loader constants: raw items (pixel, float4 column) -> 4 input + 2 dY float4 per thread
+  const int c4 = t & 15, prow = t >> 4;     // item q: pixel = prow + 16 q
+  const float* xbase = a.X + (long long)b * a.H * a.W * a.Cin + cib * 64 + c4 * 4;
+  const float* zbase = a.dZ + (long long)b * a.H * a.W * a.Cout + cob * 64 + c4 * 4;
+  int xpy[4], xpx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { const int pix = prow + 16 * q; xpy[q] = pix / 10; xpx[q] = pix - xpy[q] * 10; }
+  f32x4 gx[4], gz[2];
+  // transform item: channel tc = t & 63, part = t >> 6: tile row tr = part >> 1, tile-column pair tp = part & 1
+  const int tc = t & 63, tr = t >> 7, tp = (t >> 6) & 1;
+  const float* xr = Rw + ((2 * tr) * 10 + 4 * tp) * 64 + tc;            // 4 rows x 6 cols of the input patch
+  const float* zr = Rw + XPS * 64 + ((2 * tr) * 8 + 4 * tp) * 64 + tc;   // 2 rows x 4 cols of the dY patch
+  const int vdst = tr * SLAB + tc * 4 + 2 * tp;                        // + xi * 2 * SLAB
+
+  auto G = [&](int c) {                     // global -> registers, chunk c = tile group (gy, gx)
+    const int gy = c / a.gw, gxx = c - gy * a.gw;
+    const int iy0 = gy * 4 - 1, ix0 = gxx * 8 - 1;                      // input patch origin (pad 1)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int iy = iy0 + xpy[q], ix = ix0 + xpx[q];
+      const bool ok = (prow + 16 * q) < XP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      const f32x4 v = *(const f32x4*)(xbase + (ok ? (iy * a.W + ix) * a.Cin : 0));
+      gx[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int pix = prow + 16 * q;
+      const int oy = gy * 4 + (pix >> 3), ox = gxx * 8 + (pix & 7);
+      const bool ok = oy < a.H && ox < a.W;
+      const f32x4 v = *(const f32x4*)(zbase + (ok ? (oy * a.W + ox) * a.Cout : 0));
+      gz[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto S = [&]() {                          // registers -> raw LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *(f32x4*)(Rw + (prow + 16 * q) * 64 + c4 * 4) = gx[q];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) *(f32x4*)(Rw + (XPS + prow + 16 * q) * 64 + c4 * 4) = gz[q];
+  };
+  // raw patches -> V / Z images of buffer `buf` (this thread: channel tc, two tiles of tile row tr)
+  float xv[4][6], zv[2][4];
+  auto Tread = [&]() {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc) xv[r][cc] = xr[(r * 10 + cc) * 64];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc) zv[r][cc] = zr[(r * 8 + cc) * 64];
+  };
+  auto Tv = [&](float* vb, int half) {      // V rows 2*half, 2*half+1 of both tiles: B^T d B
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int R = 2 * half + rr;
+      float t0[6];                          // row R of B^T d for the 6 patch columns
+#pragma unroll
+      for (int cc = 0; cc < 6; ++cc)
+        t0[cc] = R == 0 ? xv[0][cc] - xv[2][cc] : R == 1 ? xv[1][cc] + xv[2][cc]
+               : R == 2 ? xv[2][cc] - xv[1][cc] : xv[3][cc] - xv[1][cc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {         // column j of (.) B for tile 0 (cols 0..3) and tile 1 (cols 2..5)
+        float o[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const float* u = t0 + 2 * tl;
+          o[tl] = j == 0 ? u[0] - u[2] : j == 1 ? u[1] + u[2] : j == 2 ? u[2] - u[1] : u[3] - u[1];
+        }
+        *(float2*)(vb + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);
+      }
+    }
+  };
+  auto Tz = [&](float* zb, int half) {      // Z rows 2*half, 2*half+1 of both tiles: G dY G^T
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int R = 2 * half + rr;
+      float t0[4];                          // row R of G dY for the 4 dY columns (2 per tile)
+#pragma unroll
+      for (int cc = 0; cc < 4; ++cc)
+        t0[cc] = R == 0 ? zv[0][cc] : R == 1 ? 0.5f * (zv[0][cc] + zv[1][cc])
+               : R == 2 ? 0.5f * (zv[0][cc] - zv[1][cc]) : zv[1][cc];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float o[2];
+#pragma unroll
+        for (int tl = 0; tl < 2; ++tl) {
+          const float* u = t0 + 2 * tl;
+          o[tl] = j == 0 ? u[0] : j == 1 ? 0.5f * (u[0] + u[1]) : j == 2 ? 0.5f * (u[0] - u[1]) : u[1];
+        }
+        *(float2*)(zb + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);
+      }
+    }
+  };
+
+  f32x16 acc[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+  // ---- prologue: chunk 0 transformed into buffer 0, chunk 1 raw in LDS, chunk 2 in flight is issued in chunk 0
+  G(0);
+  S();
+  __syncthreads();
+  Tread();
+  Tv(Vs + vdst, 0); Tv(Vs + vdst, 1); Tz(Zs + vdst, 0); Tz(Zs + vdst, 1);
+  G(nchunk > 1 ? 1 : 0);
+  __syncthreads();
+  S();
+  __syncthreads();
+
+  const int fragA = lh * SLAB + (wm * 32 + li) * 4;
+  const int fragB = lh * SLAB + (wn * 32 + li) * 4;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
+    const float* ub_ = Zs + (c & 1) * VU_BUF + fragB;
+    float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // T(c+1) (harmless after the last chunk)
+    float* zw_ = Zs + ((c + 1) & 1) * VU_BUF + vdst;
+    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;
+    const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
+    const int giy0 = ggy * 4 - 1, gix0 = ggx * 8 - 1;
+    f32x4 fa_[4], fb_[4];
+    fa_[0] = *(const f32x4*)(vb_);
+    fb_[0] = *(const f32x4*)(ub_);
+    fa_[1] = *(const f32x4*)(vb_ + 2 * SLAB);
+    fb_[1] = *(const f32x4*)(ub_ + 2 * SLAB);
+#define WGSLOT(SIDX)                                                                                \
+    {                                                                                               \
+      constexpr int sidx = (SIDX);                                                                  \
+      constexpr int xi = wino_xi(sidx), e = wino_e(sidx);                                           \
+      if (e == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (wg_younger(xi) << 8));                       \
+      acc[xi] = mfma32(fa_[xi & 3][e], fb_[xi & 3][e], acc[xi]);                                    \
+      constexpr int fp = wino_frag_pos(sidx);                                                       \
+      if (fp >= 0) {                                                                                \
+        constexpr int fq = fp >= 0 ? fp : 0;                                                        \
+        fa_[fq & 3] = *(const f32x4*)(vb_ + fq * 2 * SLAB);                                         \
+        fb_[fq & 3] = *(const f32x4*)(ub_ + fq * 2 * SLAB);                                         \
+      }                                                                                             \
+      constexpr int kind = wg_side_kind(sidx), k_ = wg_side_idx(sidx);                              \
+      if (kind == 1) {                      /* global loads of chunk c+2 */                        \
+        if (k_ < 4) {                                                                               \
+          constexpr int q = k_ < 4 ? k_ : 0;                                                        \
+          const int iy = giy0 + xpy[q], ix = gix0 + xpx[q];                                         \
+          const bool ok = (prow + 16 * q) < XP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W; \
+          const f32x4 v = *(const f32x4*)(xbase + (ok ? (iy * a.W + ix) * a.Cin : 0)); \
+          gx[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
+        } else {                                                                                    \
+          constexpr int q = k_ >= 4 ? k_ - 4 : 0;                                                   \
+          const int pix = prow + 16 * q;                                                            \
+          const int oy = ggy * 4 + (pix >> 3), ox = ggx * 8 + (pix & 7);                            \
+          const bool ok = oy < a.H && ox < a.W;                                                     \
+          const f32x4 v = *(const f32x4*)(zbase + (ok ? (oy * a.W + ox) * a.Cout : 0)); \
+          gz[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
+        }                                                                                           \
+      } else if (kind == 2) {               /* input patch rows of chunk c+1: 8 values per piece */ \
+        _Pragma("unroll") for (int i8 = 0; i8 < 8; ++i8) {                                          \
+          constexpr int dummy = 0; (void)dummy;                                                     \
+          const int idx = k_ * 8 + i8;                                                              \
+          xv[idx / 6][idx % 6] = xr[((idx / 6) * 10 + idx % 6) * 64];                               \
+        }                                                                                           \
+      } else if (kind == 3) {               /* dY patch of chunk c+1 */                            \
+        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
+          _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) zv[r][cc] = zr[(r * 8 + cc) * 64];       \
+      } else if (kind == 4) {               /* V: one row of positions for both tiles per piece */ \
+        constexpr int R = k_;                                                                       \
+        float t0[6];                                                                                \
+        _Pragma("unroll") for (int cc = 0; cc < 6; ++cc)                                            \
+          t0[cc] = R == 0 ? xv[0][cc] - xv[2][cc] : R == 1 ? xv[1][cc] + xv[2][cc]                  \
+                 : R == 2 ? xv[2][cc] - xv[1][cc] : xv[3][cc] - xv[1][cc];                          \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+          float o[2];                                                                               \
+          _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                        \
+            const float* u = t0 + 2 * tl;                                                           \
+            o[tl] = j == 0 ? u[0] - u[2] : j == 1 ? u[1] + u[2] : j == 2 ? u[2] - u[1] : u[3] - u[1]; \
+          }                                                                                         \
+          *(float2*)(vw_ + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);                       \
+        }                                                                                           \
+      } else if (kind == 5) {               /* Z: two rows of positions for both tiles per piece */ \
+        _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                          \
+          constexpr int dummy2 = 0; (void)dummy2;                                                   \
+          const int R = 2 * k_ + rr;                                                                \
+          float t0[4];                                                                              \
+          _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                          \
+            t0[cc] = R == 0 ? zv[0][cc] : R == 1 ? 0.5f * (zv[0][cc] + zv[1][cc])                   \
+                   : R == 2 ? 0.5f * (zv[0][cc] - zv[1][cc]) : zv[1][cc];                           \
+          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
+            float o[2];                                                                             \
+            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                      \
+              const float* u = t0 + 2 * tl;                                                         \
+              o[tl] = j == 0 ? u[0] : j == 1 ? 0.5f * (u[0] + u[1]) : j == 2 ? 0.5f * (u[0] - u[1]) : u[1]; \
+            }                                                                                       \
+            *(float2*)(zw_ + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);                     \
+          }                                                                                         \
+        }                                                                                           \
+      } else if (kind == 6) {               /* all waves are past their raw-patch reads */         \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        __builtin_amdgcn_s_barrier();                                                               \
+      } else if (kind == 7) {               /* chunk c+2: registers -> raw LDS, 2 float4 per piece */ \
+        if (k_ < 2) {                                                                               \
+          _Pragma("unroll") for (int q = 2 * k_; q < 2 * k_ + 2; ++q)                               \
+            *(f32x4*)(Rw + (prow + 16 * q) * 64 + c4 * 4) = gx[q];                                  \
+        } else {                                                                                    \
+          _Pragma("unroll") for (int q = 0; q < 2; ++q) *(f32x4*)(Rw + (XPS + prow + 16 * q) * 64 + c4 * 4) = gz[q]; \
+        }                                                                                           \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define WGSLOT4(B) WGSLOT((B)) WGSLOT((B) + 1) WGSLOT((B) + 2) WGSLOT((B) + 3)
+#define WGSLOT16(B) WGSLOT4((B)) WGSLOT4((B) + 4) WGSLOT4((B) + 8) WGSLOT4((B) + 12)
+    WGSLOT16(0) WGSLOT16(16) WGSLOT16(32) WGSLOT16(48)
+#undef WGSLOT16
+#undef WGSLOT4
+#undef WGSLOT
+    __syncthreads();
+  }
+
+  // ---- per-image partial dU[xi][ci][co] -> slab[b]
+  float* out = a.slab + ((long long)b * 16) * a.Cin * a.Cout;
+  const int co = cob * 64 + wn * 32 + li;
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = cib * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[((long long)xi * a.Cin + ci) * a.Cout + co] = acc[xi][r];
+    }
+}
+
+// dW[co][ci][p][q] = sum_{i,j} AT[p][i] AT[q][j] * sum_b slab[b][i*4+j][ci][co]
+__global__ void wino_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dW, int nb, int Cin, int Cout) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)Cin * Cout) return;
+  const int co = (int)(idx % Cout), ci = (int)(idx / Cout);
+  float m[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) m[xi] = 0.f;
+  for (int bb = 0; bb < nb; ++bb)
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) m[xi] += slab[(((long long)bb * 16 + xi) * Cin + ci) * Cout + co];
+  // rows: s[p][j] = sum_i AT[p][i] m[i][j], AT = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]
+  float sr[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sr[0][j] = m[0 + j] + m[4 + j] + m[8 + j];
+    sr[1][j] = m[4 + j] - m[8 + j];
+    sr[2][j] = m[4 + j] + m[8 + j] + m[12 + j];
+  }
+#pragma unroll
+  for (int p = 0; p < 3; ++p) {
+    float* o = dW + (((long long)co * Cin + ci) * 3 + p) * 3;
+    o[0] = sr[p][0] + sr[p][1] + sr[p][2];
+    o[1] = sr[p][1] - sr[p][2];
+    o[2] = sr[p][1] + sr[p][2] + sr[p][3];
+  }
+}
+
 }  // namespace
 
 extern "C" long long cy_wino_packed_floats(int Cin, int N) {
@@ -411,5 +736,28 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   if (rc) return rc;
   wino_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd");
+  return 0;
+}
+
+extern "C" long long cy_wino_wgrad_ws_floats(int B, int Cin, int Cout) { return (long long)B * 16 * Cin * Cout; }
+
+extern "C" int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int W, int Cin,
+                                         int Cout, void* stream) {
+  CY_REQUIRE(X && dZ && dW && ws && B > 0 && H > 0 && W > 0, "cy_conv3x3_winograd_wgrad: bad arguments");
+  CY_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "cy_conv3x3_winograd_wgrad: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
+  CY_REQUIRE((((uintptr_t)X | (uintptr_t)dZ) & 15) == 0, "cy_conv3x3_winograd_wgrad: operands must be 16-byte aligned");
+  WinoWgradArgs a;
+  a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.gh = (H + 3) / 4; a.gw = (W + 7) / 8;
+  const long long blocks = (long long)B * (Cin / 64) * (Cout / 64);
+  const size_t lds = (size_t)(4 * VU_BUF + RAWW_BUF) * 4;
+  int rc = cy_allow_lds(wino_wgrad_kernel, lds);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  wino_wgrad_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
+  CY_LAUNCH_CHECK("cy_conv3x3_winograd_wgrad");
+  const long long n = (long long)Cin * Cout;
+  wino_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B, Cin, Cout);
+  CY_LAUNCH_CHECK("cy_conv3x3_winograd_wgrad(finish)");
   return 0;
 }

@@ -176,6 +176,11 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
     _, Ho, Wo, Cout = dz.shape
     st = _stream()
     dW = _empty((Cout, Cin, k, k), dz)
+    if USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and not nchw and Cin % 64 == 0 and Cout % 64 == 0:
+        ws = _empty((query('cy_wino_wgrad_ws_floats', B, Cin, Cout),), dz)
+        with timer.range('conv_wino_wgrad/' + tag):
+            call('cy_conv3x3_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cin, Cout, st)
+        return dW
     a = ConvWgrad(X=x.data_ptr(), dZ=dz.data_ptr(), dW=dW.data_ptr(), slabs=None,
                   xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                   KH=k, KW=k, stride=stride, pad=pad)

@@ -98,6 +98,39 @@ def test_conv3x3_winograd_matches_direct_and_fp64(case):
     close(dx, dx2, 2e-4, 2e-4)
 
 
+@pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 64, 10, 64), (3, 64, 37, 128), (2, 256, 18, 64), (5, 64, 3, 64)])
+def test_conv3x3_winograd_wgrad_matches_direct_and_fp64(case):
+    """Winograd F(3x3,2x2) weight gradient (odd sizes: partially filled tile groups; one image = one partial sum)
+    against torch fp64 and against the direct MFMA weight-gradient kernel."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    x = rnd((B, Cin, H, H), 71)
+    w = rnd((Cout, Cin, 3, 3), 72, (1.0 / (Cin * 9)) ** 0.5)
+    wd = w.double().requires_grad_(True)
+    zr = F.conv2d(x.double(), wd, None, padding=1)
+    gz = rnd(tuple(zr.shape), 74)
+    zr.backward(gz.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    assert ops.USE_WINOGRAD
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        dw = ops.conv_wgrad(xg, gzd, 3, 1, 1, False, 'wg')
+    finally:
+        ops.timer.enabled = False
+    torch.cuda.synchronize()
+    assert 'conv_wino_wgrad/wg' in ops.timer.summary()
+    scale = wd.grad.abs().max().item()
+    close(dw, wd.grad, 2e-5, 2e-5 * scale)
+    try:
+        ops.USE_WINOGRAD = False
+        dw2 = ops.conv_wgrad(xg, gzd, 3, 1, 1)
+    finally:
+        ops.USE_WINOGRAD = True
+    close(dw, dw2, 4e-5, 4e-5 * scale)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
