@@ -5,6 +5,7 @@
 #include "capsyolo_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 int cy_set_error(int code, const char* fmt, ...);

@@ -79,7 +79,7 @@ constexpr int wino_younger(int xi) {
     n += wino_side_lds(is);
     for (int s = is + 1; s < us; ++s) n += wino_frag_lds(s) + wino_side_lds(s);
   }
-  return n > 15 ? 15 : n;
+  return n > 14 ? 14 : n;
 }
 
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
@@ -387,6 +387,16 @@ __global__ void wino_pack_kernel(const float* __restrict__ W, float* __restrict_
 // accumulator tiles each, same slot-scheduled pipeline as the forward kernel.  A chunk is 8 tiles (2 x 4):
 // its 6x10 input patch and 4x8 dY patch are staged raw in LDS (256-byte rows, fully coalesced), every thread
 // transforms two tiles of one channel of each operand into the [xi][k/4][channel][4 tiles] images.
+//
+// fp32 MFMA and fp32 VALU share the SIMD's ALUs on this chip (tools/probe/mfma_overlap.hip: every VALU
+// instruction of the same wave OR of a second wave on the SIMD adds ~3-10 cycles to the 64-cycle MFMA), so the
+// loop is written for a minimal VALU count, not only for a balanced slot schedule:
+//  * the two tiles a thread transforms are carried as float2 and every add is one v_pk_add_f32; the pairs come
+//    straight out of LDS (ds_read2st64_b32 of columns c and c+2), and go back as one ds_write_b64;
+//  * G's 0.5 factors are dropped (rows dY0, dY0+dY1, dY0-dY1, dY1) and restored exactly, as powers of two, by the
+//    finish kernel;
+//  * chunks whose patches are completely inside the image (94 % at 416x416) load through a uniform base + a
+//    per-thread constant offset: no address arithmetic, no range checks, no select before the LDS store.
 constexpr int GT = 8;                       // tiles per chunk (2 rows x 4 columns of tiles)
 constexpr int XP = 60, ZP = 32;             // raw patch pixels: 6x10 input, 4x8 dY
 constexpr int XPS = 64;                     // input patch rows allocated (4 spare: every thread stores 4 float4)
@@ -397,25 +407,29 @@ struct WinoWgradArgs {
   int B, H, W, Cin, Cout, gh, gw;           // gh x gw tile groups per image
 };
 
-constexpr int wg_side_kind(int s) {         // one piece of side work per MFMA slot
-  // 1 G (6 global loads)  2 T_x reads (3 x 8)  3 T_z reads (1 x 8)  4 V transform+writes (4 pieces)
-  // 5 Z transform+writes (2 pieces)  6 mid barrier  7 S_raw (6 LDS writes, 2 per piece)
-  if (s >= 2 && s < 8) return 1;
-  if (s >= 9 && s < 12) return 2;
-  if (s == 13) return 3;
-  if (s >= 17 && s < 21) return 4;
-  if (s >= 22 && s < 24) return 5;
-  if (s == 40) return 6;
-  if (s >= 44 && s < 47) return 7;
+// Side work of one chunk, one piece per MFMA slot:
+//   2 T    raw-patch reads of chunk c+1, two ds_read2st64_b32 per piece: dY first, then input rows 1,2,0,3   (10 pieces)
+//   5 Z    one row of G dY G^T for both tiles                                                                (4 pieces)
+//   4 V    one row of B^T d B for both tiles, rows in the order 1,2,0,3                                       (4 pieces)
+//   6      barrier: every wave is past its raw-patch reads
+//   7 S    one float4 of chunk c+2 registers -> raw LDS                                                       (6 pieces)
+//   1 G    one global load of chunk c+3 (almost a whole chunk of latency cover, one register set)             (6 pieces)
+constexpr int wg_side_kind(int s) {
+  if ((s >= 2 && s < 8) || (s >= 10 && s < 14)) return 2;
+  if (s == 14 || s == 15 || s == 18 || s == 19) return 5;
+  if (s >= 20 && s < 24) return 4;
+  if (s == 27) return 6;
+  if ((s >= 28 && s < 32) || s == 34 || s == 35) return 7;
+  if (s >= 36 && s < 42) return 1;
   return 0;
 }
 constexpr int wg_side_idx(int s) {
-  return s < 8 ? s - 2 : s < 12 ? s - 9 : s == 13 ? 0 : s < 21 ? s - 17 : s < 24 ? s - 22 : s < 44 ? 0 : s - 44;
+  return s < 8 ? s - 2 : s < 14 ? s - 4 : s < 16 ? s - 14 : s < 20 ? s - 16 : s < 24 ? s - 20 : s < 32 ? s - 28 : s < 36 ? s - 30 : s - 36;
 }
-constexpr int wg_side_lds(int s) {          // lower bound of the LDS instructions issued by the slot
+constexpr int wg_row_order(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 0 : 3; }
+constexpr int wg_side_lds(int s) {          // LOWER bound of the LDS instructions issued by the slot
   const int k = wg_side_kind(s);
-  // (b32 patch reads pair up into ds_read2st64_b32: 8 reads = 4 instructions)
-  return k == 2 ? 4 : k == 3 ? 4 : k == 4 ? 4 : k == 5 ? 8 : k == 7 ? 2 : 0;
+  return k == 2 ? 2 : k == 4 ? 4 : k == 5 ? 4 : k == 7 ? 1 : 0;
 }
 constexpr int wg_younger(int xi) {
   const int is = wino_issue(xi), us = wino_use(xi);
@@ -427,117 +441,154 @@ constexpr int wg_younger(int xi) {
     n += wg_side_lds(is);
     for (int s = is + 1; s < us; ++s) n += wino_frag_lds(s) + wg_side_lds(s);
   }
-  return n > 15 ? 15 : n;
+  return n > 14 ? 14 : n;
+}
+
+// (dword[O0 * 64], dword[O1 * 64]) from LDS byte address `addr` as ONE aligned register pair.  Plain C++ loads
+// are paired up by the compiler as it likes (adjacent columns) and then shuffled with v_mov + an immediate wait;
+// the transform below needs (column c, column c + 2).  The compiler does not count this read: the consumer slot
+// waits with an explicit s_waitcnt.
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_pair_st64(unsigned addr) {
+  f32x2 r;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1));
+  return r;
+}
+
+// two fp32 adds in one VALU instruction (the compiler splits most float2 adds into two v_add_f32)
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
 }
 
 __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][VU_BUF]   A images (input, rows = ci)
   float* Zs = smem + 2 * VU_BUF;            // [2][VU_BUF]   B images (dY, rows = co)
-  float* Rw = smem + 4 * VU_BUF;            // [XP + ZP][64] raw patches
+  float* Rw = smem + 4 * VU_BUF;            // [XPS + ZP][64] raw patches
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 31, lh = lane >> 5;
   const int ncb = a.Cout / 64, nib = a.Cin / 64;
-  const int cob = blockIdx.x % ncb;
-  const int cib = (blockIdx.x / ncb) % nib;
-  const int b = blockIdx.x / (ncb * nib);
+  // consecutive block ids go round-robin over the 8 XCDs: give each XCD a contiguous range of virtual ids, so that
+  // the nib*ncb blocks that share one image's patches also share one L2
+  int vid = blockIdx.x;
+  if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int cob = vid % ncb;
+  const int cib = (vid / ncb) % nib;
+  const int b = vid / (ncb * nib);
   const int nchunk = a.gh * a.gw;
 
-  // ---- loader constants: raw items (pixel, float4 column) -> 4 input + 2 dY float4 per thread
-  const int c4 = t & 15, prow = t >> 4;     // item q: pixel = prow + 16 q
-  const float* xbase = a.X + (long long)b * a.H * a.W * a.Cin + cib * 64 + c4 * 4;
-  const float* zbase = a.dZ + (long long)b * a.H * a.W * a.Cout + cob * 64 + c4 * 4;
+  // ---- loader: raw items (pixel = prow + 16 q, float4 column c4): 4 input + 2 dY float4 per thread
+  const int c4 = t & 15, prow = t >> 4;
+  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin + cib * 64);      // uniform
+  const char* zimg = (const char*)(a.dZ + (long long)b * a.H * a.W * a.Cout + cob * 64);    // uniform
   int xpy[4], xpx[4];
+  unsigned voffx[4], voffz[2];              // byte offsets of this thread's items from the patch origin
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { const int pix = prow + 16 * q; xpy[q] = pix / 10; xpx[q] = pix - xpy[q] * 10; }
+  for (int q = 0; q < 4; ++q) {
+    const int pix = prow + 16 * q;
+    xpy[q] = pix / 10; xpx[q] = pix - xpy[q] * 10;
+    voffx[q] = pix < XP ? (unsigned)(((xpy[q] * a.W + xpx[q]) * a.Cin + c4 * 4) * 4) : (unsigned)(c4 * 16);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pix = prow + 16 * q;
+    voffz[q] = (unsigned)((((pix >> 3) * a.W + (pix & 7)) * a.Cout + c4 * 4) * 4);
+  }
   f32x4 gx[4], gz[2];
-  // transform item: channel tc = t & 63, part = t >> 6: tile row tr = part >> 1, tile-column pair tp = part & 1
-  const int tc = t & 63, tr = t >> 7, tp = (t >> 6) & 1;
-  const float* xr = Rw + ((2 * tr) * 10 + 4 * tp) * 64 + tc;            // 4 rows x 6 cols of the input patch
-  const float* zr = Rw + XPS * 64 + ((2 * tr) * 8 + 4 * tp) * 64 + tc;   // 2 rows x 4 cols of the dY patch
-  const int vdst = tr * SLAB + tc * 4 + 2 * tp;                        // + xi * 2 * SLAB
-
-  auto G = [&](int c) {                     // global -> registers, chunk c = tile group (gy, gx)
-    const int gy = c / a.gw, gxx = c - gy * a.gw;
-    const int iy0 = gy * 4 - 1, ix0 = gxx * 8 - 1;                      // input patch origin (pad 1)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+  unsigned okm = 0;                         // slow path only: bit q: gx[q] in range, bit 4+q: gz[q]
+  bool gfast = false;                       // the chunk held in gx/gz was loaded by the fast path
+  // chunk (gy, gxx): fast when the 6x10 input patch and the 4x8 dY patch are inside the image
+  auto is_fast = [&](int gy, int gxx) {
+    return gy > 0 && gxx > 0 && gy * 4 + 5 <= a.H && gxx * 8 + 9 <= a.W;
+  };
+  auto Gx = [&](int q, int gy, int gxx, bool fast) {
+    const int iy0 = gy * 4 - 1, ix0 = gxx * 8 - 1;
+    if (fast) {
+      gx[q] = *(const f32x4*)(ximg + (size_t)((iy0 * a.W + ix0) * a.Cin) * 4 + voffx[q]);
+    } else {
       const int iy = iy0 + xpy[q], ix = ix0 + xpx[q];
       const bool ok = (prow + 16 * q) < XP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      const f32x4 v = *(const f32x4*)(xbase + (ok ? (iy * a.W + ix) * a.Cin : 0));
-      gx[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      gx[q] = *(const f32x4*)(ximg + (ok ? (unsigned)(((iy * a.W + ix) * a.Cin + c4 * 4) * 4) : 0u));
+      okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
+  };
+  auto Gz = [&](int q, int gy, int gxx, bool fast) {
+    if (fast) {
+      gz[q] = *(const f32x4*)(zimg + (size_t)((gy * 4 * a.W + gxx * 8) * a.Cout) * 4 + voffz[q]);
+    } else {
       const int pix = prow + 16 * q;
       const int oy = gy * 4 + (pix >> 3), ox = gxx * 8 + (pix & 7);
       const bool ok = oy < a.H && ox < a.W;
-      const f32x4 v = *(const f32x4*)(zbase + (ok ? (oy * a.W + ox) * a.Cout : 0));
-      gz[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      gz[q] = *(const f32x4*)(zimg + (ok ? (unsigned)(((oy * a.W + ox) * a.Cout + c4 * 4) * 4) : 0u));
+      okm = (okm & ~(16u << q)) | ((unsigned)ok << (4 + q));
     }
   };
-  auto S = [&]() {                          // registers -> raw LDS
-#pragma unroll
-    for (int q = 0; q < 4; ++q) *(f32x4*)(Rw + (prow + 16 * q) * 64 + c4 * 4) = gx[q];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) *(f32x4*)(Rw + (XPS + prow + 16 * q) * 64 + c4 * 4) = gz[q];
+  auto Sx = [&](int q) {
+    float* dst = Rw + (prow + 16 * q) * 64 + c4 * 4;
+    if (gfast) *(f32x4*)dst = gx[q];
+    else *(f32x4*)dst = (okm >> q) & 1 ? gx[q] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  // raw patches -> V / Z images of buffer `buf` (this thread: channel tc, two tiles of tile row tr)
-  float xv[4][6], zv[2][4];
-  auto Tread = [&]() {
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 6; ++cc) xv[r][cc] = xr[(r * 10 + cc) * 64];
-#pragma unroll
-    for (int r = 0; r < 2; ++r)
-#pragma unroll
-      for (int cc = 0; cc < 4; ++cc) zv[r][cc] = zr[(r * 8 + cc) * 64];
+  auto Sz = [&](int q) {
+    float* dst = Rw + (XPS + prow + 16 * q) * 64 + c4 * 4;
+    if (gfast) *(f32x4*)dst = gz[q];
+    else *(f32x4*)dst = (okm >> (4 + q)) & 1 ? gz[q] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
-  auto Tv = [&](float* vb, int half) {      // V rows 2*half, 2*half+1 of both tiles: B^T d B
+  auto Gall = [&](int c) {
+    const int gy = c / a.gw, gxx = c - gy * a.gw;
+    const bool fast = is_fast(gy, gxx);
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int R = 2 * half + rr;
-      float t0[6];                          // row R of B^T d for the 6 patch columns
+    for (int q = 0; q < 4; ++q) Gx(q, gy, gxx, fast);
 #pragma unroll
-      for (int cc = 0; cc < 6; ++cc)
-        t0[cc] = R == 0 ? xv[0][cc] - xv[2][cc] : R == 1 ? xv[1][cc] + xv[2][cc]
-               : R == 2 ? xv[2][cc] - xv[1][cc] : xv[3][cc] - xv[1][cc];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {         // column j of (.) B for tile 0 (cols 0..3) and tile 1 (cols 2..5)
-        float o[2];
-#pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-          const float* u = t0 + 2 * tl;
-          o[tl] = j == 0 ? u[0] - u[2] : j == 1 ? u[1] + u[2] : j == 2 ? u[2] - u[1] : u[3] - u[1];
-        }
-        *(float2*)(vb + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);
-      }
-    }
+    for (int q = 0; q < 2; ++q) Gz(q, gy, gxx, fast);
+    gfast = fast;
   };
-  auto Tz = [&](float* zb, int half) {      // Z rows 2*half, 2*half+1 of both tiles: G dY G^T
+  auto Sall = [&]() {
 #pragma unroll
-    for (int rr = 0; rr < 2; ++rr) {
-      const int R = 2 * half + rr;
-      float t0[4];                          // row R of G dY for the 4 dY columns (2 per tile)
+    for (int q = 0; q < 4; ++q) Sx(q);
 #pragma unroll
-      for (int cc = 0; cc < 4; ++cc)
-        t0[cc] = R == 0 ? zv[0][cc] : R == 1 ? 0.5f * (zv[0][cc] + zv[1][cc])
-               : R == 2 ? 0.5f * (zv[0][cc] - zv[1][cc]) : zv[1][cc];
+    for (int q = 0; q < 2; ++q) Sz(q);
+  };
+
+  // ---- transform item: channel tc = t & 63, tile row tr, tile-column pair tp; .x = tile 2 tp, .y = tile 2 tp + 1
+  const int tc = t & 63, tr = t >> 7, tp = (t >> 6) & 1;
+  const float* xr = Rw + ((2 * tr) * 10 + 4 * tp) * 64 + tc;            // 4 rows x 6 cols of the input patch
+  const float* zr = Rw + XPS * 64 + ((2 * tr) * 8 + 4 * tp) * 64 + tc;  // 2 rows x 4 cols of the dY patch
+  const int vdst = tr * SLAB + tc * 4 + 2 * tp;                        // + xi * 2 * SLAB
+  const unsigned xr_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)xr;
+  const unsigned zr_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)zr;
+  f32x2 xv[4][4], zv[2][2];                 // [row][col] pairs: (col, col + 2) = the same column of the two tiles
+  auto Tx = [&](int r, int c) { xv[r][c] = f32x2{xr[(r * 10 + c) * 64], xr[(r * 10 + c + 2) * 64]}; };
+  auto Tz = [&](int r, int c) { zv[r][c] = f32x2{zr[(r * 8 + c) * 64], zr[(r * 8 + c + 2) * 64]}; };
+  auto Vrow = [&](float* vb, int R) {       // row R of B^T d B
+    f32x2 t0[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        float o[2];
+    for (int c = 0; c < 4; ++c)
+      t0[c] = R == 0 ? pk_sub(xv[0][c], xv[2][c]) : R == 1 ? pk_add(xv[1][c], xv[2][c])
+            : R == 2 ? pk_sub(xv[2][c], xv[1][c]) : pk_sub(xv[3][c], xv[1][c]);
+    *(f32x2*)(vb + (R * 4 + 0) * 2 * SLAB) = pk_sub(t0[0], t0[2]);
+    *(f32x2*)(vb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[1], t0[2]);
+    *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
+    *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[3], t0[1]);
+  };
+  auto Zrow = [&](float* zb, int R) {       // row R of (2G) dY (2G)^T
+    f32x2 t0[2];
 #pragma unroll
-        for (int tl = 0; tl < 2; ++tl) {
-          const float* u = t0 + 2 * tl;
-          o[tl] = j == 0 ? u[0] : j == 1 ? 0.5f * (u[0] + u[1]) : j == 2 ? 0.5f * (u[0] - u[1]) : u[1];
-        }
-        *(float2*)(zb + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);
-      }
-    }
+    for (int c = 0; c < 2; ++c)
+      t0[c] = R == 0 ? zv[0][c] : R == 1 ? pk_add(zv[0][c], zv[1][c]) : R == 2 ? pk_sub(zv[0][c], zv[1][c]) : zv[1][c];
+    *(f32x2*)(zb + (R * 4 + 0) * 2 * SLAB) = t0[0];
+    *(f32x2*)(zb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[0], t0[1]);
+    *(f32x2*)(zb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[0], t0[1]);
+    *(f32x2*)(zb + (R * 4 + 3) * 2 * SLAB) = t0[1];
   };
 
   f32x16 acc[16];
@@ -546,15 +597,24 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
 
-  // ---- prologue: chunk 0 transformed into buffer 0, chunk 1 raw in LDS, chunk 2 in flight is issued in chunk 0
-  G(0);
-  S();
+  // ---- prologue: chunk 0 transformed into buffer 0, chunk 1 raw in LDS, chunk 2 in registers
+  Gall(0);
+  Sall();
   __syncthreads();
-  Tread();
-  Tv(Vs + vdst, 0); Tv(Vs + vdst, 1); Tz(Zs + vdst, 0); Tz(Zs + vdst, 1);
-  G(nchunk > 1 ? 1 : 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) Tx(r, c);
+#pragma unroll
+  for (int r = 0; r < 2; ++r)
+#pragma unroll
+    for (int c = 0; c < 2; ++c) Tz(r, c);
+#pragma unroll
+  for (int R = 0; R < 4; ++R) { Vrow(Vs + vdst, R); Zrow(Zs + vdst, R); }
+  Gall(nchunk > 1 ? 1 : 0);
   __syncthreads();
-  S();
+  Sall();
+  Gall(nchunk > 2 ? 2 : nchunk - 1);
   __syncthreads();
 
   const int fragA = lh * SLAB + (wm * 32 + li) * 4;
@@ -564,9 +624,9 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     const float* ub_ = Zs + (c & 1) * VU_BUF + fragB;
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // T(c+1) (harmless after the last chunk)
     float* zw_ = Zs + ((c + 1) & 1) * VU_BUF + vdst;
-    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;
+    const int cg = (c + 3 < nchunk) ? c + 3 : nchunk - 1;
     const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
-    const int giy0 = ggy * 4 - 1, gix0 = ggx * 8 - 1;
+    const bool gf_next = is_fast(ggy, ggx);
     f32x4 fa_[4], fb_[4];
     fa_[0] = *(const f32x4*)(vb_);
     fb_[0] = *(const f32x4*)(ub_);
@@ -584,72 +644,30 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
         fa_[fq & 3] = *(const f32x4*)(vb_ + fq * 2 * SLAB);                                         \
         fb_[fq & 3] = *(const f32x4*)(ub_ + fq * 2 * SLAB);                                         \
       }                                                                                             \
-      constexpr int kind = wg_side_kind(sidx), k_ = wg_side_idx(sidx);                              \
-      if (kind == 1) {                      /* global loads of chunk c+2 */                        \
-        if (k_ < 4) {                                                                               \
-          constexpr int q = k_ < 4 ? k_ : 0;                                                        \
-          const int iy = giy0 + xpy[q], ix = gix0 + xpx[q];                                         \
-          const bool ok = (prow + 16 * q) < XP && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W; \
-          const f32x4 v = *(const f32x4*)(xbase + (ok ? (iy * a.W + ix) * a.Cin : 0)); \
-          gx[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
-        } else {                                                                                    \
-          constexpr int q = k_ >= 4 ? k_ - 4 : 0;                                                   \
-          const int pix = prow + 16 * q;                                                            \
-          const int oy = ggy * 4 + (pix >> 3), ox = ggx * 8 + (pix & 7);                            \
-          const bool ok = oy < a.H && ox < a.W;                                                     \
-          const f32x4 v = *(const f32x4*)(zbase + (ok ? (oy * a.W + ox) * a.Cout : 0)); \
-          gz[q] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};                                               \
-        }                                                                                           \
-      } else if (kind == 2) {               /* input patch rows of chunk c+1: 8 values per piece */ \
-        _Pragma("unroll") for (int i8 = 0; i8 < 8; ++i8) {                                          \
-          constexpr int dummy = 0; (void)dummy;                                                     \
-          const int idx = k_ * 8 + i8;                                                              \
-          xv[idx / 6][idx % 6] = xr[((idx / 6) * 10 + idx % 6) * 64];                               \
-        }                                                                                           \
-      } else if (kind == 3) {               /* dY patch of chunk c+1 */                            \
-        _Pragma("unroll") for (int r = 0; r < 2; ++r)                                               \
-          _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) zv[r][cc] = zr[(r * 8 + cc) * 64];       \
-      } else if (kind == 4) {               /* V: one row of positions for both tiles per piece */ \
-        constexpr int R = k_;                                                                       \
-        float t0[6];                                                                                \
-        _Pragma("unroll") for (int cc = 0; cc < 6; ++cc)                                            \
-          t0[cc] = R == 0 ? xv[0][cc] - xv[2][cc] : R == 1 ? xv[1][cc] + xv[2][cc]                  \
-                 : R == 2 ? xv[2][cc] - xv[1][cc] : xv[3][cc] - xv[1][cc];                          \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
-          float o[2];                                                                               \
-          _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                        \
-            const float* u = t0 + 2 * tl;                                                           \
-            o[tl] = j == 0 ? u[0] - u[2] : j == 1 ? u[1] + u[2] : j == 2 ? u[2] - u[1] : u[3] - u[1]; \
-          }                                                                                         \
-          *(float2*)(vw_ + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);                       \
-        }                                                                                           \
-      } else if (kind == 5) {               /* Z: two rows of positions for both tiles per piece */ \
-        _Pragma("unroll") for (int rr = 0; rr < 2; ++rr) {                                          \
-          constexpr int dummy2 = 0; (void)dummy2;                                                   \
-          const int R = 2 * k_ + rr;                                                                \
-          float t0[4];                                                                              \
-          _Pragma("unroll") for (int cc = 0; cc < 4; ++cc)                                          \
-            t0[cc] = R == 0 ? zv[0][cc] : R == 1 ? 0.5f * (zv[0][cc] + zv[1][cc])                   \
-                   : R == 2 ? 0.5f * (zv[0][cc] - zv[1][cc]) : zv[1][cc];                           \
-          _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                           \
-            float o[2];                                                                             \
-            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                      \
-              const float* u = t0 + 2 * tl;                                                         \
-              o[tl] = j == 0 ? u[0] : j == 1 ? 0.5f * (u[0] + u[1]) : j == 2 ? 0.5f * (u[0] - u[1]) : u[1]; \
-            }                                                                                       \
-            *(float2*)(zw_ + (R * 4 + j) * 2 * SLAB) = make_float2(o[0], o[1]);                     \
-          }                                                                                         \
-        }                                                                                           \
-      } else if (kind == 6) {               /* all waves are past their raw-patch reads */         \
-        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
-        __builtin_amdgcn_s_barrier();                                                               \
-      } else if (kind == 7) {               /* chunk c+2: registers -> raw LDS, 2 float4 per piece */ \
+      constexpr int kind = wg_side_kind(sidx), k_ = wg_side_idx(sidx) >= 0 ? wg_side_idx(sidx) : 0; \
+      if (kind == 1) {                      /* one global load of chunk c+3 */                     \
+        if (k_ < 4) Gx(k_ & 3, ggy, ggx, gf_next); else Gz(k_ & 1, ggy, ggx, gf_next);              \
+        if (k_ == 5) gfast = gf_next;                                                               \
+      } else if (kind == 2) {               /* raw patches of chunk c+1: 2 pairs */                \
         if (k_ < 2) {                                                                               \
-          _Pragma("unroll") for (int q = 2 * k_; q < 2 * k_ + 2; ++q)                               \
-            *(f32x4*)(Rw + (prow + 16 * q) * 64 + c4 * 4) = gx[q];                                  \
+          constexpr int r = k_ & 1;                                                                 \
+          zv[r][0] = lds_pair_st64<r * 8 + 0, r * 8 + 2>(zr_a);                                     \
+          zv[r][1] = lds_pair_st64<r * 8 + 1, r * 8 + 3>(zr_a);                                     \
         } else {                                                                                    \
-          _Pragma("unroll") for (int q = 0; q < 2; ++q) *(f32x4*)(Rw + (XPS + prow + 16 * q) * 64 + c4 * 4) = gz[q]; \
+          constexpr int L = (k_ - 2) & 7, r = wg_row_order(L >> 1), c0 = 2 * (L & 1);               \
+          xv[r][c0] = lds_pair_st64<r * 10 + c0, r * 10 + c0 + 2>(xr_a);                            \
+          xv[r][c0 + 1] = lds_pair_st64<r * 10 + c0 + 1, r * 10 + c0 + 3>(xr_a);                    \
         }                                                                                           \
+      } else if (kind == 4) {               /* all patch reads are >= 14 LDS operations old */     \
+        if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (14 << 8));                                \
+        Vrow(vw_, wg_row_order(k_ & 3));                                                            \
+      } else if (kind == 5) {               /* the dY reads are >= 14 LDS operations old */        \
+        if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (14 << 8));                                \
+        Zrow(zw_, k_ & 3);                                                                          \
+      } else if (kind == 6) {               /* all waves are past their raw-patch reads */         \
+        __builtin_amdgcn_s_barrier();                                                               \
+      } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
+        if (k_ < 4) Sx(k_ & 3); else Sz(k_ & 1);                                                    \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -674,7 +692,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     }
 }
 
-// dW[co][ci][p][q] = sum_{i,j} AT[p][i] AT[q][j] * sum_b slab[b][i*4+j][ci][co]
+// dW[co][ci][p][q] = sum_{i,j} AT[p][i] AT[q][j] g_i g_j * sum_b slab[b][i*4+j][ci][co],  g = (1, .5, .5, 1) restores G's
+// factors that the main kernel leaves out
 __global__ void wino_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dW, int nb, int Cin, int Cout) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)Cin * Cout) return;
@@ -685,6 +704,11 @@ __global__ void wino_wgrad_finish_kernel(const float* __restrict__ slab, float* 
   for (int bb = 0; bb < nb; ++bb)
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi) m[xi] += slab[(((long long)bb * 16 + xi) * Cin + ci) * Cout + co];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) {
+    const int i = xi >> 2, j = xi & 3;
+    m[xi] *= ((i == 1 || i == 2) ? 0.5f : 1.f) * ((j == 1 || j == 2) ? 0.5f : 1.f);
+  }
   // rows: s[p][j] = sum_i AT[p][i] m[i][j], AT = [[1,1,1,0],[0,1,-1,0],[0,1,1,1]]
   float sr[3][4];
 #pragma unroll
