@@ -23,7 +23,7 @@ constexpr int WN = 64;                      // output channels per block
 constexpr int KC = 8;                       // input channels per chunk
 constexpr int SLAB = WT * 4 + 4;            // floats per (xi, kq) slab of V or U (16 B pad)
 constexpr int VU_BUF = 32 * SLAB;           // 16 positions x 2 k-quads
-constexpr int RAWP = 328;                   // 18*18 = 324 pixels, padded
+constexpr int RAWP = 337;                   // 18*18 = 324 pixels, padded: the k-quad stride is 4 banks (mod 64)
 constexpr int RAW_BUF = 2 * RAWP * 4;       // [kq][pixel][4]
 
 struct WinoArgs {
@@ -33,6 +33,18 @@ struct WinoArgs {
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// two fp32 adds in one VALU instruction (the compiler splits most float2 adds into two v_add_f32)
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
 }
 
 // ---- compile-time schedule of one chunk (64 slots = 64 MFMAs per wave)
@@ -45,27 +57,39 @@ constexpr int wino_use(int xi) { return 8 * (xi >> 1) + (xi & 1); }
 constexpr int wino_issue(int xi) { return wino_use(xi) - 8; }              // < 0: fetched before the loop body
 constexpr int wino_frag_pos(int s) { return ((s & 7) < 2 && s + 8 < 64) ? wino_xi(s) + 2 : -1; }   // position prefetched in slot s
 // side work, one piece per slot (see the slot body):
-//   1 S_U   U(c+1) registers -> LDS (2 pieces)      2 G_raw  patch loads of chunk c+2 (3)     3 G_U  U loads of c+2 (8)
-//   4 T_rd  patch rows of chunk c+1 from LDS (3)     5 T_bt   rows of B^T d (8)                6 T_v  V positions (8)
-//   7 S_raw patch of chunk c+2 registers -> LDS (3)
+//   1 S_U   U(c+1) registers -> LDS (2 pieces)      7 S_raw  patch of chunk c+2 registers -> LDS (3)
+//   2 G_raw patch loads of chunk c+3 (3), right after their registers were stored: a whole chunk of latency cover
+//   3 G_U   U loads of c+2 (8)
+//   4 T_rd  patch of chunk c+1 from LDS, two float2 per piece, rows in the order 1,2,0,3 (8)
+//   5 T_v   one row of V = B^T d B: 8 packed adds + 4 LDS writes (4, rows in the order 1,2,0,3)
+// pieces of different kinds are interleaved and the loads spread out: 11 global loads in consecutive slots back up
+// the CU's one vector-memory pipeline (a patch load touches 32 cache lines) and the stalled wave stops issuing MFMAs
+constexpr int wino_find(const int* list, int n, int s) {
+  for (int i = 0; i < n; ++i) if (list[i] == s) return i;
+  return -1;
+}
+constexpr int WS_SU[2] = {0, 1};
+constexpr int WS_GU[8] = {2, 4, 6, 10, 12, 14, 18, 20};
+constexpr int WS_TRD[8] = {3, 5, 7, 11, 13, 15, 19, 21};
+constexpr int WS_TV[4] = {23, 27, 29, 31};
+constexpr int WS_SRAW[3] = {34, 36, 38};
+constexpr int WS_GRAW[3] = {42, 44, 46};
 constexpr int wino_side_kind(int s) {
-  if (s < 2) return 1;
-  if (s < 5) return 2;
-  if (s < 13) return 3;
-  if (s < 16) return 4;
-  if (s >= 17 && s < 25) return 5;
-  if (s >= 26 && s < 34) return 6;
-  if (s >= 44 && s < 47) return 7;
-  return 0;
+  return wino_find(WS_SU, 2, s) >= 0 ? 1 : wino_find(WS_GRAW, 3, s) >= 0 ? 2 : wino_find(WS_GU, 8, s) >= 0 ? 3
+       : wino_find(WS_TRD, 8, s) >= 0 ? 4 : wino_find(WS_TV, 4, s) >= 0 ? 5 : wino_find(WS_SRAW, 3, s) >= 0 ? 7 : 0;
 }
 constexpr int wino_side_idx(int s) {
-  return s < 2 ? s : s < 5 ? s - 2 : s < 13 ? s - 5 : s < 16 ? s - 13 : s < 25 ? s - 17 : s < 34 ? s - 26 : s - 44;
+  const int k = wino_side_kind(s);
+  return k == 1 ? wino_find(WS_SU, 2, s) : k == 2 ? wino_find(WS_GRAW, 3, s) : k == 3 ? wino_find(WS_GU, 8, s)
+       : k == 4 ? wino_find(WS_TRD, 8, s) : k == 5 ? wino_find(WS_TV, 4, s) : k == 7 ? wino_find(WS_SRAW, 3, s) : 0;
 }
+constexpr int wino_row_order(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 0 : 3; }
 constexpr int wino_side_lds(int s) {
   const int k = wino_side_kind(s);
   // a LOWER bound of the LDS instructions the slot issues (the waits below may never allow more outstanding
-  // operations than are really younger): the S_raw store is exec-masked and may be skipped by a whole wave
-  return (k == 1 || k == 4) ? 4 : (k == 6) ? 1 : 0;
+  // operations than are really younger): two float2 reads may merge into one ds_read2_b64, the last S_raw store
+  // is exec-masked and may be skipped by a whole wave
+  return (k == 1 || k == 5) ? 4 : (k == 4) ? 1 : (k == 7 && wino_side_idx(s) < 2) ? 1 : 0;
 }
 constexpr int wino_frag_lds(int s) { return wino_frag_pos(s) >= 0 ? 2 : 0; }
 // LDS operations younger than position xi's fragments when its first MFMA issues (s_waitcnt lgkmcnt operand)
@@ -82,6 +106,7 @@ constexpr int wino_younger(int xi) {
   return n > 14 ? 14 : n;
 }
 
+template <int EXP>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][VU_BUF]
@@ -102,27 +127,38 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int oy0 = tby * 16, ox0 = tbx * 16;
 
   // ---- per-thread constants of the loaders
-  // raw patch: item = pixel*2 + kq (32 B contiguous per pixel), 648 items over 256 threads
+  // raw patch: 648 float4 items over 256 threads x 3; 32 consecutive items = 16 pixels x 2 k-quads with the pixel in
+  // the low 4 bits, so that the 16 lanes of one ds_write_b128 pass hit 16 different pixels of one k-quad (no bank
+  // conflict) while a wave's global load still covers both 16-byte halves of each pixel's 32 bytes
   long long goff[3]; bool gok[3]; int roff[3];
+  unsigned gvoff[3];                        // fast path: byte offset from the image's first pixel (block inside the image)
+  const bool blk_fast = oy0 >= 1 && ox0 >= 1 && oy0 + 17 <= a.H && ox0 + 17 <= a.W;    // uniform
+  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);             // uniform
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int item = t + 256 * q;
-    const int pix = item >> 1, kq = item & 1;
+    const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
+    const bool valid = pix < 324;
     const int py = pix / 18, px = pix - py * 18;
     const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-    gok[q] = item < 648 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+    gok[q] = valid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
     goff[q] = (((long long)b * a.H + iy) * a.W + ix) * a.Cin + kq * 4;
-    roff[q] = item < 648 ? (kq * RAWP + pix) * 4 : -1;
+    gvoff[q] = (blk_fast && valid) ? (unsigned)(((iy * a.W + ix) * a.Cin + kq * 4) * 4) : 0u;
+    roff[q] = valid ? (kq * RAWP + pix) * 4 : -1;
   }
   // U chunk: 32 segments (xi*2+kq) of 64 channels x float4; thread -> float4 f = t + 256q
   const float* usrc = a.U + ((long long)(t >> 6) * a.Np + nb * WN + (t & 63)) * 4;   // segment t>>6 (+4 per q)
   const long long useg = (long long)4 * a.Np * 4;      // 4 segments further per q
   const long long uchunk = (long long)32 * a.Np * 4;
+  const unsigned uvoff = (unsigned)(((t >> 6) * a.Np + nb * WN + (t & 63)) * 16);      // bytes from the chunk's first float
   const int uoff = (t >> 6) * SLAB + (t & 63) * 4;     // + 4*SLAB per q
-  // transform item: tile = t & 63, kq = (t >> 6) & 1, rh = t >> 7 (rows 2rh, 2rh+1 of V)
-  const int ttile = t & 63, tkq = (t >> 6) & 1, trh = t >> 7;
-  const int tbase = (tkq * RAWP + (2 * (ttile >> 3) + trh) * 18 + 2 * (ttile & 7)) * 4;   // row `trh` of the 4x4 patch
-  const int vdst = ((2 * trh) * 4 * 2 + tkq) * SLAB + ttile * 4;                          // xi = (2rh)*4 + c -> + c*2*SLAB
+  // transform item: channel pair tch = t & 1 of k-quad tkq = (t >> 1) & 1, tile column (t >> 2) & 7, tile row t >> 5:
+  // the thread computes all 16 positions of V for two channels, every add is one v_pk_add_f32 on a float2 that came
+  // out of LDS as a pair.  With RAWP = 1 (mod 16) the 64 lanes of one float2 patch read (offsets 2 tch + 4 tkq +
+  // 8 tx + 16 ty_low mod 64 banks) are 2-way conflicted, the minimum for 512 bytes (8-way with tile-major lanes).
+  const int tch = t & 1, tkq = (t >> 1) & 1, ttile = t >> 2;
+  const int tbase = (tkq * RAWP + (2 * (ttile >> 3)) * 18 + 2 * (ttile & 7)) * 4 + 2 * tch;   // patch pixel (0,0)
+  const int vdst = tkq * SLAB + ttile * 4 + 2 * tch;                                          // + xi * 2 * SLAB
 
   f32x4 graw[3], gu[8];
   const int nchunk = a.Cin / KC;
@@ -132,13 +168,17 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   auto Graw = [&](int c, f32x4 (&dst)[3]) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const f32x4 v = *(const f32x4*)(a.X + ((gok[q] ? goff[q] : 0ll) + (long long)c * KC));
-      dst[q] = gok[q] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (blk_fast) {
+        dst[q] = *(const f32x4*)(ximg + (size_t)c * (KC * 4) + gvoff[q]);
+      } else {
+        const f32x4 v = *(const f32x4*)(a.X + ((gok[q] ? goff[q] : 0ll) + (long long)c * KC));
+        dst[q] = gok[q] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
     }
   };
   auto GU = [&](int c, f32x4 (&dst)[8]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dst[q] = *(const f32x4*)(usrc + (long long)c * uchunk + q * useg);
+    for (int q = 0; q < 8; ++q) dst[q] = *(const f32x4*)((const char*)a.U + ((long long)c * uchunk + q * useg) * 4 + uvoff);
   };
   auto Sraw = [&](int c, const f32x4 (&src)[3]) {   // registers -> LDS raw patch buffer c & 1
     float* rb = Rs + (c & 1) * RAW_BUF;
@@ -151,32 +191,27 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) *(f32x4*)(ub + uoff + q * 4 * SLAB) = src[q];
   };
-  auto T = [&](int c) {                     // raw patch -> two rows of V = B^T d B (this thread's tile, 4 channels)
+  f32x2 xv[4][4];                           // the thread's 4x4 patch, two channels
+  auto Vrow = [&](float* vb, int R) {       // row R of V = B^T d B
+    f32x2 t0[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      t0[cc] = R == 0 ? pk_sub(xv[0][cc], xv[2][cc]) : R == 1 ? pk_add(xv[1][cc], xv[2][cc])
+             : R == 2 ? pk_sub(xv[2][cc], xv[1][cc]) : pk_sub(xv[1][cc], xv[3][cc]);
+    *(f32x2*)(vb + (R * 4 + 0) * 2 * SLAB) = pk_sub(t0[0], t0[2]);
+    *(f32x2*)(vb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[1], t0[2]);
+    *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
+    *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[1], t0[3]);
+  };
+  auto T = [&](int c) {                     // raw patch -> V (this thread's tile, 2 channels)
     const float* rb = Rs + (c & 1) * RAW_BUF + tbase;
-    f32x4 x0[4], x1[4], x2[4];
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      x0[cc] = *(const f32x4*)(rb + cc * 4);
-      x1[cc] = *(const f32x4*)(rb + (18 + cc) * 4);
-      x2[cc] = *(const f32x4*)(rb + (36 + cc) * 4);
-    }
-    // rows of B^T d:  rh=0: (d0 - d2, d1 + d2) from rows (0,1,2);  rh=1: (d2 - d1, d1 - d3) from rows (1,2,3)
-    f32x4 tA[4], tB[4];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-    for (int cc = 0; cc < 4; ++cc) {
-      tA[cc] = trh ? (x1[cc] - x0[cc]) : (x0[cc] - x2[cc]);
-      tB[cc] = trh ? (x0[cc] - x2[cc]) : (x1[cc] + x2[cc]);
-    }
+      for (int cc = 0; cc < 4; ++cc) xv[r][cc] = *(const f32x2*)(rb + (r * 18 + cc) * 4);
     float* vb = Vs + (c & 1) * VU_BUF + vdst;
-    // columns of (.) B:  (t0 - t2, t1 + t2, t2 - t1, t1 - t3)
-    *(f32x4*)(vb + 0 * 2 * SLAB) = tA[0] - tA[2];
-    *(f32x4*)(vb + 1 * 2 * SLAB) = tA[1] + tA[2];
-    *(f32x4*)(vb + 2 * 2 * SLAB) = tA[2] - tA[1];
-    *(f32x4*)(vb + 3 * 2 * SLAB) = tA[1] - tA[3];
-    *(f32x4*)(vb + 4 * 2 * SLAB) = tB[0] - tB[2];
-    *(f32x4*)(vb + 5 * 2 * SLAB) = tB[1] + tB[2];
-    *(f32x4*)(vb + 6 * 2 * SLAB) = tB[2] - tB[1];
-    *(f32x4*)(vb + 7 * 2 * SLAB) = tB[1] - tB[3];
+#pragma unroll
+    for (int R = 0; R < 4; ++R) Vrow(vb, R);
   };
 
   f32x16 acc[16];
@@ -186,7 +221,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
 
   // ---- prologue.  Pipeline state at the top of chunk c: V[c&1] = transformed chunk c, U[c&1] = weights of chunk c,
-  // raw[(c+1)&1] = input patch of chunk c+1, registers gu = weights of chunk c+1.  Both chunks' global loads are
+  // raw[(c+1)&1] = input patch of chunk c+1, registers gu = weights of chunk c+1, graw = patch of chunk c+2.  Both chunks' global loads are
   // issued back to back so that the block pays one memory round trip.
   {
     f32x4 graw1[3];
@@ -195,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     GU(0, gu);
     Graw(c1, graw1);
     Sraw(0, graw);
+    Graw(nchunk > 2 ? 2 : nchunk - 1, graw);
     SU(0, gu);
     GU(c1, gu);
     __syncthreads();
@@ -216,12 +252,13 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     const float* ub_ = Us + (c & 1) * VU_BUF + fragB;
     const float* rb_ = Rs + ((c + 1) & 1) * RAW_BUF + tbase;        // T(c+1) reads ...
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last chunk)
-    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G(c+2), clamped: the last chunks re-load valid data
-    const long long gx = (long long)cg * KC;
-    const float* gusrc = usrc + (long long)cg * uchunk;
+    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G_U(c+2), clamped: the last chunks re-load valid data
+    const int cgr = (c + 3 < nchunk) ? c + 3 : nchunk - 1;          // G_raw(c+3)
+    const long long gx = (long long)cgr * KC;
+    const char* gxfast = ximg + (size_t)cgr * (KC * 4);               // uniform
+    const char* gusrc = (const char*)a.U + (long long)cg * uchunk * 4;  // uniform
     float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(c+1) (harmless after the last chunk)
     float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(c+2) -> raw[(c+2)&1]
-    f32x4 x0_[4], x1_[4], x2_[4], tA_[4], tB_[4];
     f32x4 fa_[4], fb_[4];                   // fragment sets, indexed by position & 3
     fa_[0] = *(const f32x4*)(vb_);
     fb_[0] = *(const f32x4*)(ub_);
@@ -234,36 +271,33 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       if (e == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (wino_younger(xi) << 8));                     \
       acc[xi] = mfma32(fa_[xi & 3][e], fb_[xi & 3][e], acc[xi]);                                    \
       constexpr int fp = wino_frag_pos(sidx);                                                       \
-      if (fp >= 0) {                                                                                \
+      if (fp >= 0 && !(EXP & 8)) {                                                                                \
         constexpr int fq = fp >= 0 ? fp : 0;                                                        \
         fa_[fq & 3] = *(const f32x4*)(vb_ + fq * 2 * SLAB);                                         \
         fb_[fq & 3] = *(const f32x4*)(ub_ + fq * 2 * SLAB);                                         \
       }                                                                                             \
       constexpr int kind = wino_side_kind(sidx), k_ = wino_side_idx(sidx);                          \
-      if (kind == 1) {                      /* U(c+1): registers -> LDS, 4 float4 per piece */     \
+      if (kind == 1 && !(EXP & 4)) {        /* U(c+1): registers -> LDS, 4 float4 per piece */     \
         _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
           *(f32x4*)(uw_ + (k_ * 4 + q) * 4 * SLAB) = gu[k_ * 4 + q];                                \
-      } else if (kind == 2) {               /* patch loads of chunk c+2 */                         \
-        const f32x4 v_ = *(const f32x4*)(a.X + ((gok[k_] ? goff[k_] : 0ll) + gx));                  \
-        graw[k_] = gok[k_] ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                        \
-      } else if (kind == 3) {               /* weight loads of chunk c+2 */                        \
-        gu[k_] = *(const f32x4*)(gusrc + k_ * useg);                                                \
-      } else if (kind == 4) {               /* patch rows of chunk c+1 */                          \
-        if (k_ == 0) { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x0_[cc] = *(const f32x4*)(rb_ + cc * 4); } \
-        else if (k_ == 1) { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x1_[cc] = *(const f32x4*)(rb_ + (18 + cc) * 4); } \
-        else { _Pragma("unroll") for (int cc = 0; cc < 4; ++cc) x2_[cc] = *(const f32x4*)(rb_ + (36 + cc) * 4); } \
-      } else if (kind == 5) {               /* rows of B^T d: patch column k_>>1 */                 \
-        constexpr int cc = k_ >> 1;                                                                 \
-        if ((k_ & 1) == 0) tA_[cc] = trh ? (x1_[cc] - x0_[cc]) : (x0_[cc] - x2_[cc]);               \
-        else tB_[cc] = trh ? (x0_[cc] - x2_[cc]) : (x1_[cc] + x2_[cc]);                             \
-      } else if (kind == 6) {               /* columns of (.) B: one V position per slot */         \
-        const f32x4* tt_ = (k_ < 4) ? tA_ : tB_;                                                    \
-        constexpr int cj_ = k_ & 3;                                                                 \
-        const f32x4 v_ = cj_ == 0 ? (tt_[0] - tt_[2]) : cj_ == 1 ? (tt_[1] + tt_[2])                \
-                       : cj_ == 2 ? (tt_[2] - tt_[1]) : (tt_[1] - tt_[3]);                          \
-        *(f32x4*)(vw_ + k_ * 2 * SLAB) = v_;                                                        \
-      } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
-        if (roff[k_] >= 0) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                    \
+      } else if (kind == 2 && !(EXP & 1)) { /* patch loads of chunk c+3 */                         \
+        if (blk_fast) {                                                                             \
+          graw[k_] = *(const f32x4*)(gxfast + gvoff[k_]);                                           \
+        } else {                                                                                    \
+          const f32x4 v_ = *(const f32x4*)(a.X + ((gok[k_] ? goff[k_] : 0ll) + gx));                \
+          graw[k_] = gok[k_] ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
+        }                                                                                           \
+      } else if (kind == 3 && !(EXP & 1)) { /* weight loads of chunk c+2 */                        \
+        gu[k_] = *(const f32x4*)(gusrc + k_ * (useg * 4) + uvoff);                                  \
+      } else if (kind == 4 && !(EXP & 2)) { /* patch of chunk c+1: two float2 */                   \
+        constexpr int r_ = wino_row_order((k_ >> 1) & 3), c0_ = 2 * (k_ & 1);                       \
+        xv[r_][c0_] = *(const f32x2*)(rb_ + (r_ * 18 + c0_) * 4);                                   \
+        xv[r_][c0_ + 1] = *(const f32x2*)(rb_ + (r_ * 18 + c0_ + 1) * 4);                           \
+      } else if (kind == 5 && !(EXP & 2)) { /* one row of V */                                     \
+        Vrow(vw_, wino_row_order(k_ & 3));                                                          \
+      } else if (kind == 7 && !(EXP & 4)) { /* patch of chunk c+2: registers -> LDS */             \
+        if (k_ < 2) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                           \
+        else if (roff[k_] >= 0) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                               \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -276,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     __syncthreads();                        // the only barrier of the chunk
   }
 
+  if (EXP & 16) { if (acc[0][0] == 12345.f && acc[7][3] == 1.f) a.Y[0] = acc[3][2]; return; }
   // ---- output transform (lane-local): Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
   // The wave's 32 tiles x 32 channels (128 pixels) go through its private 16 KiB of LDS so that the global
   // stores are 16 bytes per lane (8 lanes per pixel): 16 store instructions per lane instead of 64 -- the
@@ -306,6 +341,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       if (vy) { ssum += y10; ssq += y10 * y10; }
       if (vx && vy) { ssum += y11; ssq += y11 * y11; }
     }
+    __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: keeps the 256 accumulator reads from piling up
   }
   {
     const int c4 = lane & 7;
@@ -452,18 +488,6 @@ template <int O0, int O1>
 __device__ __forceinline__ f32x2 lds_pair_st64(unsigned addr) {
   f32x2 r;
   asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1));
-  return r;
-}
-
-// two fp32 adds in one VALU instruction (the compiler splits most float2 adds into two v_add_f32)
-__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-  return r;
-}
-__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
 
@@ -756,9 +780,14 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / WN);
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv3x3_winograd: grid too large");
   const size_t lds = (size_t)(4 * VU_BUF + 2 * RAW_BUF) * 4;
-  int rc = cy_allow_lds(wino_conv_kernel, lds);
+  const char* ev = getenv("CY_WF_EXP");
+  const int ex = ev ? atoi(ev) : 0;
+  int rc = cy_allow_lds(wino_conv_kernel<0>, lds);
   if (rc) return rc;
-  wino_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+#define WF_CASE(E) else if (ex == E) { cy_allow_lds(wino_conv_kernel<E>, lds); wino_conv_kernel<E><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a); }
+  if (ex == 0) wino_conv_kernel<0><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  WF_CASE(1) WF_CASE(2) WF_CASE(3) WF_CASE(7) WF_CASE(15) WF_CASE(16) WF_CASE(31) WF_CASE(4) WF_CASE(8)
+#undef WF_CASE
   CY_LAUNCH_CHECK("cy_conv3x3_winograd");
   return 0;
 }
