@@ -55,16 +55,16 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
   if (s == 12345.678f) out[t] = s + lds[t];
 }
 template <int KIND, int EVERY>
-void run(float* out, const float* in, int cus, const char* name) {
+void run(float* out, const float* in, int cus, const char* name, int wps = 1) {
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int iters = 10000;
-  k<KIND, EVERY><<<cus, 256>>>(out, in, 1000, 1.0f, 0.5f);
+  k<KIND, EVERY><<<cus * wps, 256>>>(out, in, 1000, 1.0f, 0.5f);
   (void)hipEventRecord(e0);
-  k<KIND, EVERY><<<cus, 256>>>(out, in, iters, 1.0f, 0.5f);
+  k<KIND, EVERY><<<cus * wps, 256>>>(out, in, iters, 1.0f, 0.5f);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
-  const double cyc = ms * 1e-3 * 2.37e9 / (iters * 16.0);
-  printf("%-44s every %d MFMA: %6.1f cycles per MFMA slot  -> %6.1f extra cycles per side instruction\n", name, EVERY, cyc,
+  const double cyc = ms * 1e-3 * 2.37e9 / (iters * 16.0 * wps);
+  printf("waves/SIMD %d  %-44s every %d MFMA: %6.1f cycles per MFMA slot  -> %6.1f extra cycles per side instruction\n", wps, name, EVERY, cyc,
          (cyc - 64.3) * EVERY);
 }
 int main() {
@@ -84,6 +84,15 @@ int main() {
   run<3, 4>(out, in, nb, "global_load_dwordx4 coalesced");
   run<4, 1>(out, in, nb, "global_load_dwordx4 32 B pieces");
   run<4, 4>(out, in, nb, "global_load_dwordx4 32 B pieces");
+  run<0, 1>(out, in, nb, "none", 2);
+  run<3, 1>(out, in, nb, "global_load_dwordx4 coalesced", 2);
+  run<3, 4>(out, in, nb, "global_load_dwordx4 coalesced", 2);
+  run<4, 4>(out, in, nb, "global_load_dwordx4 32 B pieces", 2);
+  run<6, 1>(out, in, nb, "ds_read_b64 32 B stride (8-way conflict)", 2);
+  run<9, 1>(out, in, nb, "ds_read_b64 contiguous", 2);
+  run<2, 1>(out, in, nb, "ds_read_b128", 2);
+  run<8, 1>(out, in, nb, "4 x v_add_f32", 2);
+  run<7, 1>(out, in, nb, "4 x v_pk_add_f32", 2);
   run<7, 1>(out, in, nb, "4 x v_pk_add_f32");
   run<8, 1>(out, in, nb, "4 x v_add_f32");
   return 0;
