@@ -30,6 +30,22 @@ PEAK_FP32_MATRIX_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f
 PEAK_HBM_GBPS = 8000.0               # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def pmc_traffic():
+    """HBM bytes per launch measured with rocprofv3 PMC passes (tools/pmc_traffic.py -> profiles/*_pmc_traffic.json);
+    the newest file wins.  bench.py cannot collect counters itself: it only reports what was measured."""
+    import glob
+    best = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic.json'))):
+        try:
+            with open(f) as fh:
+                d = json.load(fh)
+            for k, v in d.get('kernels', {}).items():
+                best[k] = dict(v, source=os.path.basename(f))
+        except Exception:
+            pass
+    return best
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -160,6 +176,7 @@ def main():
         M = B * args.input * args.input
         conv2_flops = 2.0 * M * 256 * (9 * 128)          # algorithmic: 2*Cin*k^2*Cout*Ho*Wo per image
         # conv_2's three kernels (77.5 % of the model's FLOPs); the dominant one by time carries `roofline`
+        pmc = pmc_traffic()
         cands = []
         for key, kname, executed in (
                 ('conv_wino_fwd/conv_2', 'wino_conv_kernel (conv_2 forward, fused Winograd F(2x2,3x3), fp32 MFMA)', 1 / 2.25),
@@ -172,7 +189,11 @@ def main():
                 n, ms = kt[key]
                 ach = conv2_flops / (ms * 1e-3) / 1e12
                 cands.append({'kernel': kname, 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MATRIX_TFLOPS,
-                              'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MATRIX_TFLOPS, 4), 'traffic': None,
+                              'unit': 'TFLOP/s', 'frac': round(ach / PEAK_FP32_MATRIX_TFLOPS, 4),
+                              'traffic': pmc[key]['bytes'] if key in pmc else None,
+                              'traffic_source': (pmc[key]['source'] + ': 2 x FETCH_SIZE + WRITE_SIZE bytes per launch; '
+                                                 'algorithmic input+output+weights = %.2f GB' % ((M * (128 + 256) * 4 + 1152 * 256 * 4) / 1e9))
+                              if key in pmc else None,
                               'launch_ms': round(ms, 4), 'launches_timed': n,
                               'executed_frac': round(ach * executed / PEAK_FP32_MATRIX_TFLOPS, 4),
                               'note': 'achieved = direct-convolution FLOPs (M=%d, N=256, K=1152: %.3f TFLOP) / launch time; '
@@ -196,7 +217,9 @@ def main():
             'roofline_routing': {'kernel': 'caps1_fwd_kernel<5,true> (fused routing, C=1, cell gather folded into the load; '
                                            'launch_ms includes the HIP-event bracket, rocprof: profiles/)',
                                  'bound': 'hbm', 'achieved': round(rt_gbps, 1), 'peak': PEAK_HBM_GBPS, 'unit': 'GB/s',
-                                 'frac': round(rt_gbps / PEAK_HBM_GBPS, 4), 'traffic': None,
+                                 'frac': round(rt_gbps / PEAK_HBM_GBPS, 4),
+                                 'traffic': pmc['routing_fwd']['bytes'] if 'routing_fwd' in pmc else None,
+                                 'algorithmic_bytes': int(rt_bytes),
                                  'launch_ms': round(msr, 5), 'launches_timed': nr},
             'kernel_ms': dict((k, round(v[1], 4)) for k, v in sorted(kt.items())),
         }

@@ -117,9 +117,13 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 31, lh = lane >> 5;
 
+  // consecutive block ids go round-robin over the 8 XCDs: give each XCD a contiguous range of virtual ids, so that
+  // the Np/64 blocks that read the same 18x18 patch run on one XCD and share its L2
+  unsigned vid = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int nblk = a.Np / WN;
-  const int nb = blockIdx.x % nblk;
-  int rest = blockIdx.x / nblk;
+  const int nb = vid % nblk;
+  int rest = vid / nblk;
   const int tbx = rest % a.tbw; rest /= a.tbw;
   const int tby = rest % a.tbh;
   const int b = rest / a.tbh;
