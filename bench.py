@@ -172,6 +172,31 @@ def main():
         elapsed = float(t.item())
     kt = ops.timer.summary()
 
+    # PCIe-inclusive rate (never `value`): the same step fed from host memory through the device-side input pipeline
+    # (uint8 over PCIe, double-buffered, converted on the GPU) -- what main.py's loop does per batch
+    from capsyolo_amd.input_pipeline import DeviceFeeder, quantize_if_exact
+    n_h2d = min(args.steps, 10)
+    x_host = quantize_if_exact(synth.images(B, args.input, first=lo))      # once per data set, as main.py does
+    y_host = synth.gtsdb_labels(B, g, 43, first=lo)
+    feeder = DeviceFeeder([(x_host, y_host)] * (n_h2d + 1), dev)
+    it = iter(feeder)
+    xb, yb = next(it)
+
+    def step_on(xb, yb):
+        out = net(xb)
+        l = loss_fns.darkcapsule_loss(out, yb, p)
+        opt.zero_grad()
+        l.backward()
+        bucket.allreduce_mean()
+        opt.step()
+    step_on(xb, yb)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for xb, yb in it:
+        step_on(xb, yb)
+    torch.cuda.synchronize()
+    h2d_elapsed = time.perf_counter() - t1
+
     if rank == 0:
         M = B * args.input * args.input
         conv2_flops = 2.0 * M * 256 * (9 * 128)          # algorithmic: 2*Cin*k^2*Cout*Ho*Wo per image
@@ -221,6 +246,11 @@ def main():
                                  'traffic': pmc['routing_fwd']['bytes'] if 'routing_fwd' in pmc else None,
                                  'algorithmic_bytes': int(rt_bytes),
                                  'launch_ms': round(msr, 5), 'launches_timed': nr},
+            'pcie_inclusive': {'value': round(world * B * n_h2d / h2d_elapsed, 3), 'unit': 'images/s (this rank x world)',
+                               'ms_per_step': round(1e3 * h2d_elapsed / n_h2d, 3), 'steps': n_h2d,
+                               'h2d_bytes_per_step': int(x_host.size + y_host.nbytes),
+                               'note': 'batch fed from host memory every step: uint8 over PCIe, pinned double buffer, '
+                                       'centring + NHWC->NCHW on the device (capsyolo_amd/input_pipeline.py)'},
             'kernel_ms': dict((k, round(v[1], 4)) for k, v in sorted(kt.items())),
         }
         if world == 1 and not args.no_cpu_baseline:

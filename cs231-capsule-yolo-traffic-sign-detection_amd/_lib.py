@@ -72,6 +72,7 @@ _SIGS = {
     'cy_recon_loss_add': [_P, _P, _F, _P, _P, _L, _P],
     'cy_dark_loss': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _P],
     'cy_scale_by_device_scalar': [_P, _P, _P, _L, _P],
+    'cy_center_u8': [_P, _P, _I, _I, _I, _I, _I, _P],
     'cy_permute4': [_P, _P, _L, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'cy_maxpool2_fwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'cy_maxpool2_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],

@@ -15,6 +15,19 @@ inline unsigned grid_for(long long n) {
 #define CY_GRID_STRIDE(i, n) \
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (long long)gridDim.x * blockDim.x)
 
+// uint8 NHWC image batch -> centred fp32 (x - 128) / 128 (utils.py:122-123), NCHW (what model.forward takes,
+// main.py:57-59) or NHWC.  One thread converts 4 consecutive bytes of one pixel row segment.
+__global__ void center_u8_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, long long npix, int C,
+                                 long long HW, int to_nchw) {
+  CY_GRID_STRIDE(i, npix * C) {
+    const float v = ((float)src[i] - 128.0f) * 0.0078125f;
+    if (!to_nchw) { dst[i] = v; continue; }
+    const long long p = i / C; const int c = (int)(i - p * C);
+    const long long b = p / HW, r = p - b * HW;
+    dst[(b * C + c) * HW + r] = v;
+  }
+}
+
 // generic 4-D permute: out[b][i1][i2][i3] (contiguous) = in[b*sb + i1*s1 + i2*s2 + i3*s3]
 __global__ void permute4_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int d1, int d2, int d3,
                                 long long sb, long long s1, long long s2, long long s3, int scatter) {
@@ -143,6 +156,13 @@ __global__ void pick_capsule_kernel(const float* __restrict__ caps, const long l
 
 #define CY_S ((hipStream_t)stream)
 
+extern "C" int cy_center_u8(const unsigned char* src, float* dst, int B, int H, int W, int C, int to_nchw, void* stream) {
+  CY_REQUIRE(src && dst && B > 0 && H > 0 && W > 0 && C > 0, "cy_center_u8: bad arguments");
+  const long long npix = (long long)B * H * W;
+  center_u8_kernel<<<grid_for(npix * C), 256, 0, CY_S>>>(src, dst, npix, C, (long long)H * W, to_nchw);
+  CY_LAUNCH_CHECK("cy_center_u8");
+  return 0;
+}
 extern "C" int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,
                            long long s2, long long s3, int scatter, void* stream) {
   CY_REQUIRE(in && out && nb > 0 && d1 > 0 && d2 > 0 && d3 > 0, "cy_permute4: bad arguments");

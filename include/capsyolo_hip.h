@@ -172,6 +172,10 @@ int cy_scale_by_device_scalar(const float* in, const float* scalar, float* out, 
  * Layout permutes standing in for the reference's view/permute/cat glue (models.py:8-19, 80-82):
  * out[b][i1][i2][i3] (contiguous, dims nb x d1 x d2 x d3) = in[b*sb + i1*s1 + i2*s2 + i3*s3];
  * scatter=1 runs the inverse (in is contiguous, out is strided): the backward of the gather. */
+/* Device side of the input pipeline: uint8 NHWC [B,H,W,C] -> fp32 (x - 128) / 128, the centring of
+ * utils.py:122-123, written NCHW (to_nchw = 1: the layout main.py:57-59 hands to model.forward) or NHWC.  Exact:
+ * every value is k / 128.  Lets the host ship 1 byte per sample instead of 4 (GTSRB) or 8 (GTSDB float64). */
+int cy_center_u8(const unsigned char* src, float* dst, int B, int H, int W, int C, int to_nchw, void* stream);
 int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,
                 long long s2, long long s3, int scatter, void* stream);
 /* nn.MaxPool2d(2) on NHWC (models.py:135-195): x [B,2Ho,2Wo,C] -> y [B,Ho,Wo,C]; idx keeps the argmax (0..3) */

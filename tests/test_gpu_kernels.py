@@ -360,3 +360,31 @@ def test_misc_ops():
     (yh * G3.to(dev())).sum().backward()
     close(yh, ref, 1e-5, 1e-6)
     close(hh.grad, hr.grad, 1e-4, 1e-5)
+
+
+def test_center_u8_and_device_feeder_match_reference_expression():
+    """cy_center_u8 and the double-buffered feeder give exactly torch.from_numpy(x).float().permute(0,3,1,2)
+    (main.py:57-59) for uint8-representable data (float32 and float64 storage) and for augmented floats."""
+    from capsyolo_amd import _lib
+    from capsyolo_amd.input_pipeline import DeviceFeeder, quantize_if_exact
+    rng = np.random.default_rng(11)
+    u = rng.integers(0, 256, (5, 12, 10, 3), dtype=np.uint8)
+    ud = torch.from_numpy(u).to(dev())
+    for to_nchw in (0, 1):
+        out = torch.empty((5, 3, 12, 10) if to_nchw else (5, 12, 10, 3), device=dev())
+        _lib.call('cy_center_u8', ud.data_ptr(), out.data_ptr(), 5, 12, 10, 3, to_nchw, torch.cuda.current_stream().cuda_stream)
+        ref = (torch.from_numpy(u).float() - 128.0) / 128.0
+        assert torch.equal(out.cpu(), ref.permute(0, 3, 1, 2).contiguous() if to_nchw else ref)
+    x64 = (u.astype(np.float64) - 128.0) / 128.0
+    xaug = x64.astype(np.float32) * np.float32(1.03)
+    y = rng.random((5, 2, 2, 48))
+    assert np.array_equal(quantize_if_exact(x64), u) and quantize_if_exact(xaug) is None
+    for x in (x64, x64.astype(np.float32), xaug, u):
+        splits = list(zip(np.array_split(x, 3), np.array_split(y, 3)))
+        got = [(a.clone(), b.clone()) for a, b in DeviceFeeder(splits, 'cuda')]
+        assert len(got) == 3
+        for (xa, ya), (xb, yb) in zip(got, splits):
+            xf = (xb.astype(np.float32) - 128.0) / 128.0 if xb.dtype == np.uint8 else xb
+            want = torch.from_numpy(np.ascontiguousarray(xf)).float().permute(0, 3, 1, 2).contiguous()
+            assert xa.dtype == torch.float32 and torch.equal(xa.cpu(), want)
+            assert torch.equal(ya.cpu(), torch.from_numpy(yb))

@@ -161,3 +161,23 @@ def test_registry_and_cli_surface():
         assert os.path.exists(os.path.join(REPO, config.model_dir[name], 'params.json'))
     p = m.load_params(os.path.join(REPO, 'experiments', 'darkcapsule_416'), args)
     assert p.n_grid == 13 and p.darknet_input == 416 and p.n_iter == 3 and p.recon is False
+
+
+def test_input_pipeline_quantize_if_exact():
+    """Centred image arrays of the reference's builders ((u8 - 128) / 128, float32 or float64) go back to uint8
+    losslessly; anything else (augmented data) is refused."""
+    from capsyolo_amd.input_pipeline import quantize_if_exact
+    rng = np.random.default_rng(3)
+    u = rng.integers(0, 256, (2, 5, 7, 3), dtype=np.uint8)
+    for dt in (np.float32, np.float64):
+        x = ((u.astype(np.float64) - 128.0) / 128.0).astype(dt)
+        q = quantize_if_exact(x)
+        assert q is not None and q.dtype == np.uint8 and np.array_equal(q, u)
+        back = ((q.astype(np.float32) - 128.0) * np.float32(0.0078125))
+        assert np.array_equal(back, x.astype(np.float32))
+    assert quantize_if_exact(u) is u
+    x = ((u.astype(np.float64) - 128.0) / 128.0)
+    x[0, 0, 0, 0] += 1e-3
+    assert quantize_if_exact(x) is None
+    assert quantize_if_exact(x * 3.0) is None
+    assert quantize_if_exact(np.zeros((0, 4, 4, 3), np.float32)) is None
