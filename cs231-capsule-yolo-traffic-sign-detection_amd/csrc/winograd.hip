@@ -29,6 +29,7 @@ constexpr int RAW_BUF = 2 * RAWP * 4;       // [kq][pixel][4]
 struct WinoArgs {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
   int B, H, W, Cin, Cout, Np, tbh, tbw;
+  int ntiles;                               // B * tbh * tbw * Np/64 output tiles, walked by a persistent grid
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -45,6 +46,14 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
   f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
   return r;
+}
+
+// One accumulator element, read where the statement stands.  Plain `acc[xi][r]` lets the compiler copy ALL 16
+// accumulator vectors AGPR -> VGPR in front of the output transform (256 VGPRs: everything else is spilled).
+__device__ __forceinline__ float acc_elem(float a_elem) {
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem));
+  return x;
 }
 
 // ---- compile-time schedule of one chunk (64 slots = 64 MFMAs per wave)
@@ -117,43 +126,71 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 31, lh = lane >> 5;
 
-  // consecutive block ids go round-robin over the 8 XCDs: give each XCD a contiguous range of virtual ids, so that
-  // the Np/64 blocks that read the same 18x18 patch run on one XCD and share its L2
+  // Persistent grid (one block per CU): block j walks the tiles vid(j), vid(j) + G, vid(j) + 2G, ... as ONE
+  // continuous stream of chunks: while the MFMAs of a tile's last chunks run, the loads and the input transform of the
+  // next tile's first chunks are already in flight, so only the accumulator drain (output transform + stores)
+  // separates two tiles -- no per-tile prologue latency, no block launch gap (338 tiles per CU at the headline shape).
+  // Consecutive block ids go round-robin over the 8 XCDs: each XCD gets a contiguous range of virtual ids, so that the
+  // Np/64 tiles that read the same 18x18 patch are worked on at the same time on ONE XCD and share its L2.
   unsigned vid = blockIdx.x;
   if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int nblk = a.Np / WN;
-  const int nb = vid % nblk;
-  int rest = vid / nblk;
-  const int tbx = rest % a.tbw; rest /= a.tbw;
-  const int tby = rest % a.tbh;
-  const int b = rest / a.tbh;
-  const int oy0 = tby * 16, ox0 = tbx * 16;
+  const int ntile_mine = (a.ntiles - (int)vid + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= ntiles)
+  const int nchunk = a.Cin / KC;
+  struct TilePos { int nb, b, oy0, ox0; };
+  auto tile_pos = [&](int k) {              // k-th tile of this block (uniform)
+    const int id = (int)vid + k * (int)gridDim.x;
+    TilePos p;
+    p.nb = id % nblk;
+    int rest = id / nblk;
+    const int tbx = rest % a.tbw; rest /= a.tbw;
+    const int tby = rest % a.tbh;
+    p.b = rest / a.tbh; p.oy0 = tby * 16; p.ox0 = tbx * 16;
+    return p;
+  };
 
-  // ---- per-thread constants of the loaders
+  // ---- per-thread constants of the loaders (those of the raw-patch loader belong to the tile its stream is in)
   // raw patch: 648 float4 items over 256 threads x 3; 32 consecutive items = 16 pixels x 2 k-quads with the pixel in
   // the low 4 bits, so that the 16 lanes of one ds_write_b128 pass hit 16 different pixels of one k-quad (no bank
   // conflict) while a wave's global load still covers both 16-byte halves of each pixel's 32 bytes
   long long goff[3]; bool gok[3]; int roff[3];
-  unsigned gvoff[3];                        // fast path: byte offset from the image's first pixel (block inside the image)
-  const bool blk_fast = oy0 >= 1 && ox0 >= 1 && oy0 + 17 <= a.H && ox0 + 17 <= a.W;    // uniform
-  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);             // uniform
+  unsigned gvoff[3];                        // fast path: byte offset from the image's first pixel (tile inside the image)
+  bool blk_fast = false;                    // uniform
+  const char* ximg = nullptr;               // uniform
+  int rpy[3], rpx[3]; bool rvalid[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     const int item = t + 256 * q;
     const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
-    const bool valid = pix < 324;
-    const int py = pix / 18, px = pix - py * 18;
-    const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-    gok[q] = valid && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-    goff[q] = (((long long)b * a.H + iy) * a.W + ix) * a.Cin + kq * 4;
-    gvoff[q] = (blk_fast && valid) ? (unsigned)(((iy * a.W + ix) * a.Cin + kq * 4) * 4) : 0u;
-    roff[q] = valid ? (kq * RAWP + pix) * 4 : -1;
+    rvalid[q] = pix < 324;
+    rpy[q] = pix / 18; rpx[q] = pix - rpy[q] * 18;
+    roff[q] = rvalid[q] ? (kq * RAWP + pix) * 4 : -1;
   }
+  auto set_raw_tile = [&](int k) {
+    const TilePos p = tile_pos(k);
+    blk_fast = p.oy0 >= 1 && p.ox0 >= 1 && p.oy0 + 17 <= a.H && p.ox0 + 17 <= a.W;
+    ximg = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int kq = ((t + 256 * q) >> 4) & 1;
+      const int iy = p.oy0 - 1 + rpy[q], ix = p.ox0 - 1 + rpx[q];
+      gok[q] = rvalid[q] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      goff[q] = (((long long)p.b * a.H + iy) * a.W + ix) * a.Cin + kq * 4;
+      gvoff[q] = (blk_fast && rvalid[q]) ? (unsigned)(((iy * a.W + ix) * a.Cin + kq * 4) * 4) : 0u;
+    }
+  };
+  // stream cursors (tile index within this block, chunk): advance by one chunk, stop at the very last chunk
+  auto advance = [&](int& k, int& c) {
+    if (c + 1 < nchunk) { ++c; return false; }
+    if (k + 1 < ntile_mine) { ++k; c = 0; return true; }
+    return false;
+  };
   // U chunk: 32 segments (xi*2+kq) of 64 channels x float4; thread -> float4 f = t + 256q
-  const float* usrc = a.U + ((long long)(t >> 6) * a.Np + nb * WN + (t & 63)) * 4;   // segment t>>6 (+4 per q)
   const long long useg = (long long)4 * a.Np * 4;      // 4 segments further per q
   const long long uchunk = (long long)32 * a.Np * 4;
-  const unsigned uvoff = (unsigned)(((t >> 6) * a.Np + nb * WN + (t & 63)) * 16);      // bytes from the chunk's first float
+  const unsigned uvoff = (unsigned)(((t >> 6) * a.Np + (t & 63)) * 16);   // bytes from the chunk's first float of the co block
+  const char* ubase = nullptr;              // uniform: a.U + first output channel of the U stream's tile
+  auto set_u_tile = [&](int k) { ubase = (const char*)(a.U + (long long)tile_pos(k).nb * WN * 4); };
   const int uoff = (t >> 6) * SLAB + (t & 63) * 4;     // + 4*SLAB per q
   // transform item: channel pair tch = t & 1 of k-quad tkq = (t >> 1) & 1, tile column (t >> 2) & 7, tile row t >> 5:
   // the thread computes all 16 positions of V for two channels, every add is one v_pk_add_f32 on a float2 that came
@@ -164,7 +201,6 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int vdst = tkq * SLAB + ttile * 4 + 2 * tch;                                          // + xi * 2 * SLAB
 
   f32x4 graw[3], gu[8];
-  const int nchunk = a.Cin / KC;
 
   // global -> registers (unconditional loads: out-of-image pixels read a valid address and are zeroed, so the
   // chunk body stays straight-line code and hipcc's vmcnt counts stay exact)
@@ -181,7 +217,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   };
   auto GU = [&](int c, f32x4 (&dst)[8]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) dst[q] = *(const f32x4*)((const char*)a.U + ((long long)c * uchunk + q * useg) * 4 + uvoff);
+    for (int q = 0; q < 8; ++q) dst[q] = *(const f32x4*)(ubase + ((long long)c * uchunk + q * useg) * 4 + uvoff);
   };
   auto Sraw = [&](int c, const f32x4 (&src)[3]) {   // registers -> LDS raw patch buffer c & 1
     float* rb = Rs + (c & 1) * RAW_BUF;
@@ -217,51 +253,59 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     for (int R = 0; R < 4; ++R) Vrow(vb, R);
   };
 
-  f32x16 acc[16];
-#pragma unroll
-  for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
-
-  // ---- prologue.  Pipeline state at the top of chunk c: V[c&1] = transformed chunk c, U[c&1] = weights of chunk c,
-  // raw[(c+1)&1] = input patch of chunk c+1, registers gu = weights of chunk c+1, graw = patch of chunk c+2.  Both chunks' global loads are
-  // issued back to back so that the block pays one memory round trip.
+  // ---- prologue (once per block).  Pipeline state at the top of stream position f (tile km, chunk cm):
+  // V[f&1] / U[f&1] = transformed input / weights of position f, raw[(f+1)&1] = input patch of position f+1,
+  // registers gu = weights of position f+1, graw = patch of position f+2; the cursors (ku, cu) and (kr, cr) stand
+  // at the positions whose loads are issued during f: f+2 for U, f+3 for the patch.
+  int km = 0, cm = 0, ku = 0, cu = 0, kr = 0, cr = 0;
   {
     f32x4 graw1[3];
-    const int c1 = nchunk > 1 ? 1 : 0;
+    set_raw_tile(0);
+    set_u_tile(0);
     Graw(0, graw);
     GU(0, gu);
-    Graw(c1, graw1);
+    if (advance(kr, cr)) set_raw_tile(kr);
+    Graw(cr, graw1);
     Sraw(0, graw);
-    Graw(nchunk > 2 ? 2 : nchunk - 1, graw);
+    if (advance(kr, cr)) set_raw_tile(kr);
+    Graw(cr, graw);
     SU(0, gu);
-    GU(c1, gu);
+    if (advance(ku, cu)) set_u_tile(ku);
+    GU(cu, gu);
     __syncthreads();
     T(0);
     Sraw(1, graw1);
     __syncthreads();
+    if (advance(kr, cr)) set_raw_tile(kr);
+    if (advance(ku, cu)) set_u_tile(ku);
   }
   const int fragA = lh * SLAB + (wm * 32 + li) * 4;
   const int fragB = lh * SLAB + (wm * 0 + wn * 32 + li) * 4;
   // One chunk = 64 MFMAs per wave.  There is ONE wave per SIMD, and a wave issues in order: while it waits to
   // issue the next MFMA (the pipe is busy for 64 cycles) nothing behind that MFMA can issue.  So every other
-  // piece of work of the pipeline -- fragment reads for the next position, the input transform of chunk c+1
-  // (LDS reads, adds, LDS writes) and the global loads of chunk c+2 -- is cut into ~40 small pieces and ONE
-  // piece is placed after each MFMA in program order (pinned with sched_barrier), where it executes in that
-  // MFMA's shadow.  LDS operations complete in order, so the fragments of position xi+1 (read right after
-  // position xi's first MFMA) are ready when `lgkmcnt(0)` is checked three MFMAs later.
-  for (int c = 0; c < nchunk; ++c) {
+  // piece of work of the pipeline -- fragment reads for the next position, the input transform of position f+1
+  // (LDS reads, adds, LDS writes) and the global loads of positions f+2 / f+3 -- is cut into ~30 small pieces and
+  // ONE piece is placed after each MFMA in program order (pinned with sched_barrier).  LDS operations complete in
+  // order, so the fragments of position xi+1 (read right after position xi's first MFMA) are ready when
+  // `lgkmcnt(N)` is checked.
+  int c_next = 0;                           // stream position f (only its parity is used)
+  for (km = 0; km < ntile_mine; ++km) {
+  f32x16 acc[16];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+  for (cm = 0; cm < nchunk; ++cm, ++c_next) {
+    const int c = c_next;
     const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
     const float* ub_ = Us + (c & 1) * VU_BUF + fragB;
-    const float* rb_ = Rs + ((c + 1) & 1) * RAW_BUF + tbase;        // T(c+1) reads ...
-    float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last chunk)
-    const int cg = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G_U(c+2), clamped: the last chunks re-load valid data
-    const int cgr = (c + 3 < nchunk) ? c + 3 : nchunk - 1;          // G_raw(c+3)
-    const long long gx = (long long)cgr * KC;
-    const char* gxfast = ximg + (size_t)cgr * (KC * 4);               // uniform
-    const char* gusrc = (const char*)a.U + (long long)cg * uchunk * 4;  // uniform
-    float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(c+1) (harmless after the last chunk)
-    float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(c+2) -> raw[(c+2)&1]
+    const float* rb_ = Rs + ((c + 1) & 1) * RAW_BUF + tbase;        // T(f+1) reads ...
+    float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last position)
+    const long long gx = (long long)cr * KC;                        // G_raw(f+3) (the cursors stop at the last position:
+    const char* gxfast = ximg + (size_t)cr * (KC * 4);              //  the tail re-loads valid data), uniform
+    const char* gusrc = ubase + (long long)cu * uchunk * 4;         // G_U(f+2), uniform
+    float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(f+1) (harmless after the last position)
+    float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(f+2) -> raw[(f+2)&1]
     f32x4 fa_[4], fb_[4];                   // fragment sets, indexed by position & 3
     fa_[0] = *(const f32x4*)(vb_);
     fb_[0] = *(const f32x4*)(ub_);
@@ -311,95 +355,108 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #undef WSLOT4
 #undef WSLOT
     __syncthreads();                        // the only barrier of the chunk
-  }
-
-  // ---- output transform (lane-local): Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
-  // The wave's 32 tiles x 32 channels (128 pixels) go through its private 16 KiB of LDS so that the global
-  // stores are 16 bytes per lane (8 lanes per pixel): 16 store instructions per lane instead of 64 -- the
-  // store tail of a one-block-per-CU kernel is issue-bound and nothing overlaps it.
-  const int co = nb * WN + wn * 32 + li;
-  const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-  float ssum = 0.f, ssq = 0.f;
-  float* ow = smem + wave * 4096;           // [pixel = tile*4 + 2a + b][32 channels]
-  const bool has_stats = a.stats != nullptr;                                                       // uniform
-  const bool full = oy0 + 16 <= a.H && ox0 + 16 <= a.W && nb * WN + WN <= a.Cout && (a.Cout & 3) == 0;   // uniform
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;       // tile within the wave's 32
-    float s0[4], s1[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
-      s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
-    }
-    const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
-    const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
-    float* op = ow + tloc * 128 + li;
-    op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
-    if (has_stats) {
-      if (full) {
-        ssum += (y00 + y01) + (y10 + y11);
-        ssq = __builtin_fmaf(y00, y00, __builtin_fmaf(y01, y01, __builtin_fmaf(y10, y10, __builtin_fmaf(y11, y11, ssq))));
-      } else {
-        const int tl = wm * 32 + tloc;
-        const int oy = oy0 + 2 * (tl >> 3), ox = ox0 + 2 * (tl & 7);
-        if (co < a.Cout && oy < a.H && ox < a.W) {            // statistics over the outputs that exist
-          const bool vx = ox + 1 < a.W, vy = oy + 1 < a.H;
-          ssum += y00; ssq += y00 * y00;
-          if (vx) { ssum += y01; ssq += y01 * y01; }
-          if (vy) { ssum += y10; ssq += y10 * y10; }
-          if (vx && vy) { ssum += y11; ssq += y11 * y11; }
-        }
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: keeps the 256 accumulator reads from piling up
+    if (advance(kr, cr)) set_raw_tile(kr);
+    if (advance(ku, cu)) set_u_tile(ku);
   }
   {
-    const int c4 = lane & 7;
-    const int cbase = nb * WN + wn * 32 + c4 * 4;
-    const bool vec_ok = (a.Cout & 3) == 0;
-    if (full) {                             // whole block inside the image: one base pointer, no checks
-      float* ybase = a.Y + (((long long)b * a.H + oy0) * a.W + ox0) * a.Cout + cbase;
+    // ======== tile km is complete: drain the accumulators (c is now the position of the next tile's first chunk)
+    const int c = c_next - 1;
+    // ---- output transform (lane-local): Y = A^T M A, A^T = [[1,1,1,0],[0,1,-1,-1]]
+    // The wave's 32 tiles x 32 channels (128 pixels) go through its private 16 KiB of LDS so that the global
+    // stores are 16 bytes per lane (8 lanes per pixel): 16 store instructions per lane instead of 64 -- the
+    // store tail of a one-block-per-CU kernel is issue-bound and nothing overlaps it.
+    const TilePos tp = tile_pos(km);
+    const int nb = tp.nb, b = tp.b, oy0 = tp.oy0, ox0 = tp.ox0;
+    const int co = nb * WN + wn * 32 + li;
+    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+    float ssum = 0.f, ssq = 0.f;
+    // scratch: V[f&1] (waves 0,1) and U[f&1] (waves 2,3) were consumed by this position's MFMAs; V/U[(f+1)&1] already
+    // hold the next tile's first chunk and must survive
+    float* ow = (wave < 2 ? Vs : Us) + (c & 1) * VU_BUF + (wave & 1) * 4096;   // [pixel = tile*4 + 2a + b][32 channels]
+    const bool has_stats = a.stats != nullptr;                                                       // uniform
+    const bool full = oy0 + 16 <= a.H && ox0 + 16 <= a.W && nb * WN + WN <= a.Cout && (a.Cout & 3) == 0;   // uniform
+  #pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;       // tile within the wave's 32
+      float s0[4], s1[4];
 #pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int p = it * 8 + (lane >> 3);
-        const int tl = wm * 32 + (p >> 2), ab = p & 3;
-        const int dy = 2 * (tl >> 3) + (ab >> 1), dx = 2 * (tl & 7) + (ab & 1);
-        *(f32x4*)(ybase + (dy * a.W + dx) * a.Cout) = *(const f32x4*)(ow + p * 32 + c4 * 4);
+      for (int j = 0; j < 4; ++j) {
+        const float m0 = acc_elem(acc[0 + j][r]), m1 = acc_elem(acc[4 + j][r]), m2 = acc_elem(acc[8 + j][r]),
+                    m3 = acc_elem(acc[12 + j][r]);
+        s0[j] = m0 + m1 + m2;
+        s1[j] = m1 - m2 - m3;
       }
-    } else {
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {
-        const int p = it * 8 + (lane >> 3);                   // pixel of the wave: tile*4 + 2a + b
-        const int tloc = p >> 2, ab = p & 3;
-        const int tl = wm * 32 + tloc;
-        const int oy = oy0 + 2 * (tl >> 3) + (ab >> 1), ox = ox0 + 2 * (tl & 7) + (ab & 1);
-        const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
-        if (oy < a.H && ox < a.W) {
-          float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + cbase;
-          if (vec_ok && cbase + 3 < a.Cout) *(f32x4*)yp = v;
-          else {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (cbase + k < a.Cout) yp[k] = v[k];
+      const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+      const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+      float* op = ow + tloc * 128 + li;
+      op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
+      if (has_stats) {
+        if (full) {
+          ssum += (y00 + y01) + (y10 + y11);
+          ssq = __builtin_fmaf(y00, y00, __builtin_fmaf(y01, y01, __builtin_fmaf(y10, y10, __builtin_fmaf(y11, y11, ssq))));
+        } else {
+          const int tl = wm * 32 + tloc;
+          const int oy = oy0 + 2 * (tl >> 3), ox = ox0 + 2 * (tl & 7);
+          if (co < a.Cout && oy < a.H && ox < a.W) {            // statistics over the outputs that exist
+            const bool vx = ox + 1 < a.W, vy = oy + 1 < a.H;
+            ssum += y00; ssq += y00 * y00;
+            if (vx) { ssum += y01; ssq += y01 * y01; }
+            if (vy) { ssum += y10; ssq += y10 * y10; }
+            if (vx && vy) { ssum += y11; ssq += y11 * y11; }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: keeps the 256 accumulator reads from piling up
+    }
+    {
+      const int c4 = lane & 7;
+      const int cbase = nb * WN + wn * 32 + c4 * 4;
+      const bool vec_ok = (a.Cout & 3) == 0;
+      if (full) {                             // whole block inside the image: one base pointer, no checks
+        float* ybase = a.Y + (((long long)b * a.H + oy0) * a.W + ox0) * a.Cout + cbase;
+  #pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int p = it * 8 + (lane >> 3);
+          const int tl = wm * 32 + (p >> 2), ab = p & 3;
+          const int dy = 2 * (tl >> 3) + (ab >> 1), dx = 2 * (tl & 7) + (ab & 1);
+          *(f32x4*)(ybase + (dy * a.W + dx) * a.Cout) = *(const f32x4*)(ow + p * 32 + c4 * 4);
+        }
+      } else {
+  #pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int p = it * 8 + (lane >> 3);                   // pixel of the wave: tile*4 + 2a + b
+          const int tloc = p >> 2, ab = p & 3;
+          const int tl = wm * 32 + tloc;
+          const int oy = oy0 + 2 * (tl >> 3) + (ab >> 1), ox = ox0 + 2 * (tl & 7) + (ab & 1);
+          const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
+          if (oy < a.H && ox < a.W) {
+            float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + cbase;
+            if (vec_ok && cbase + 3 < a.Cout) *(f32x4*)yp = v;
+            else {
+  #pragma unroll
+              for (int k = 0; k < 4; ++k) if (cbase + k < a.Cout) yp[k] = v[k];
+            }
           }
         }
       }
     }
+      if (a.stats != nullptr) {
+      float* red = Rs + ((c + 1) & 1) * RAW_BUF;   // [2 wm][WN][2] in the raw buffer T(f+1) is done with
+      ssum += __shfl_xor(ssum, 32, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (lh == 0) {
+        red[(wm * WN + wn * 32 + li) * 2 + 0] = ssum;
+        red[(wm * WN + wn * 32 + li) * 2 + 1] = ssq;
+      }
+      __syncthreads();
+      if (t < WN && nb * WN + t < a.Cout) {
+        atomicAdd(a.stats + 2 * (nb * WN + t), (double)red[t * 2] + (double)red[(WN + t) * 2]);
+        atomicAdd(a.stats + 2 * (nb * WN + t) + 1, (double)red[t * 2 + 1] + (double)red[(WN + t) * 2 + 1]);
+      }
+    }
+
+    __syncthreads();                        // scratch and `red` are rewritten by the next position's T / S_raw
   }
-  __syncthreads();                          // the statistics reduction below reuses the LDS
-  if (a.stats != nullptr) {
-    float* red = smem;                      // [2 wm][WN][2]; all LDS readers are past the loop's last barrier
-    ssum += __shfl_xor(ssum, 32, 64);
-    ssq += __shfl_xor(ssq, 32, 64);
-    if (lh == 0) {
-      red[(wm * WN + wn * 32 + li) * 2 + 0] = ssum;
-      red[(wm * WN + wn * 32 + li) * 2 + 1] = ssq;
-    }
-    __syncthreads();
-    if (t < WN && nb * WN + t < a.Cout) {
-      atomicAdd(a.stats + 2 * (nb * WN + t), (double)red[t * 2] + (double)red[(WN + t) * 2]);
-      atomicAdd(a.stats + 2 * (nb * WN + t) + 1, (double)red[t * 2 + 1] + (double)red[(WN + t) * 2 + 1]);
-    }
   }
 }
 
@@ -799,8 +856,14 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.Np = (Cout + 63) / 64 * 64;
   a.tbh = (H + 15) / 16; a.tbw = (W + 15) / 16;
-  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / WN);
-  CY_REQUIRE(blocks < (1ll << 31), "cy_conv3x3_winograd: grid too large");
+  const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / WN);
+  CY_REQUIRE(tiles < (1ll << 31), "cy_conv3x3_winograd: too many tiles");
+  a.ntiles = (int)tiles;
+  int dev = 0, ncu = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "cy_conv3x3_winograd: cannot query the CU count: %s", hipGetErrorString(he));
+  const long long blocks = tiles < ncu ? tiles : ncu;   // persistent: one block per CU (155 KB of LDS, 512 registers per lane)
   const size_t lds = (size_t)(4 * VU_BUF + 2 * RAW_BUF) * 4;
   int rc = cy_allow_lds(wino_conv_kernel, lds);
   if (rc) return rc;
