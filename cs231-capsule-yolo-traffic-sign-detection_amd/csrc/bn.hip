@@ -40,12 +40,45 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
 
 __device__ __forceinline__ float lrelu(float y, float slope) { return y > 0.f ? y : y * slope; }
 
-// A = lrelu(Z*scale + shift); float4 path when N % 4 == 0
-template <bool AFFINE>
+// A = lrelu(Z*scale + shift); float4 path when N % 4 == 0.
+// HOIST (N divides 1024): the grid stride is a multiple of N, so a thread always sees the same 4 channels: their
+// scale / shift live in registers and the loop body is 4 independent 16-byte loads, the arithmetic, 4 stores --
+// no 64-bit modulo, no parameter reloads per element (those, not HBM, limited the first version to 4.6 TB/s).
+template <bool AFFINE, bool HOIST>
 __global__ void affine_act_kernel(const float* __restrict__ Z, float* __restrict__ A, const float* __restrict__ scale,
                                   const float* __restrict__ shift, float slope, long long n4, int N) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (HOIST) {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (AFFINE) {
+      const int c = (int)((threadIdx.x * 4u) % (unsigned)N);
+      sc = *(const float4*)(scale + c); sh = *(const float4*)(shift + c);
+    }
+    const f32x4* Zv = (const f32x4*)Z;
+    f32x4* Av = (f32x4*)A;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+      f32x4 z[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) z[u] = __builtin_nontemporal_load(Zv + i + u * stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 y;
+        y[0] = lrelu(z[u][0] * sc.x + sh.x, slope); y[1] = lrelu(z[u][1] * sc.y + sh.y, slope);
+        y[2] = lrelu(z[u][2] * sc.z + sh.z, slope); y[3] = lrelu(z[u][3] * sc.w + sh.w, slope);
+        __builtin_nontemporal_store(y, Av + i + u * stride);
+      }
+    }
+    for (; i < n4; i += stride) {
+      const f32x4 z = Zv[i];
+      f32x4 y;
+      y[0] = lrelu(z[0] * sc.x + sh.x, slope); y[1] = lrelu(z[1] * sc.y + sh.y, slope);
+      y[2] = lrelu(z[2] * sc.z + sh.z, slope); y[3] = lrelu(z[3] * sc.w + sh.w, slope);
+      Av[i] = y;
+    }
+    return;
+  }
+  for (; i < n4; i += stride) {
     float4 z = ((const float4*)Z)[i];
     if (AFFINE) {
       const int c = (int)((i * 4) % N);
@@ -85,19 +118,33 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ Z, const float* _
   long long r1 = r0 + rows_per_block;
   if (r1 > P) r1 = P;
   float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-  for (long long r = r0 + rsub; r < r1; r += rpar) {
-    const float4 z = *(const float4*)(Z + r * N + c);
-    const float4 g = *(const float4*)(dA + r * N + c);
-#define CY_ACC(f)                                                   \
+#define CY_ACC(z, g, f)                                             \
     {                                                               \
       const float y = z.f * sc.f + sh.f;                            \
       const float d = y > 0.f ? g.f : g.f * slope;                  \
       s1.f += d;                                                    \
       s2.f += d * ((z.f - mu.f) * is.f);                            \
     }
-    CY_ACC(x) CY_ACC(y) CY_ACC(z) CY_ACC(w)
-#undef CY_ACC
+  long long r = r0 + rsub;
+  const long long step = (long long)rpar * N;
+  const float* zp = Z + r * N + c;
+  const float* gp = dA + r * N + c;
+  for (; r + 3 * rpar < r1; r += 4 * rpar, zp += 4 * step, gp += 4 * step) {   // 8 independent 16-byte loads in flight
+    const float4 z0 = *(const float4*)(zp), z1 = *(const float4*)(zp + step), z2 = *(const float4*)(zp + 2 * step),
+                 z3 = *(const float4*)(zp + 3 * step);
+    const float4 g0 = *(const float4*)(gp), g1 = *(const float4*)(gp + step), g2 = *(const float4*)(gp + 2 * step),
+                 g3 = *(const float4*)(gp + 3 * step);
+    CY_ACC(z0, g0, x) CY_ACC(z0, g0, y) CY_ACC(z0, g0, z) CY_ACC(z0, g0, w)
+    CY_ACC(z1, g1, x) CY_ACC(z1, g1, y) CY_ACC(z1, g1, z) CY_ACC(z1, g1, w)
+    CY_ACC(z2, g2, x) CY_ACC(z2, g2, y) CY_ACC(z2, g2, z) CY_ACC(z2, g2, w)
+    CY_ACC(z3, g3, x) CY_ACC(z3, g3, y) CY_ACC(z3, g3, z) CY_ACC(z3, g3, w)
   }
+  for (; r < r1; r += rpar, zp += step, gp += step) {
+    const float4 z = *(const float4*)(zp);
+    const float4 g = *(const float4*)(gp);
+    CY_ACC(z, g, x) CY_ACC(z, g, y) CY_ACC(z, g, z) CY_ACC(z, g, w)
+  }
+#undef CY_ACC
   float* my = sm + t * 8;
   my[0] = s1.x; my[1] = s1.y; my[2] = s1.z; my[3] = s1.w;
   my[4] = s2.x; my[5] = s2.y; my[6] = s2.z; my[7] = s2.w;
@@ -112,12 +159,49 @@ __global__ void bn_bwd_reduce_kernel(const float* __restrict__ Z, const float* _
   }
 }
 
+template <bool HOIST>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ Z, const float* __restrict__ dA, float* __restrict__ dZ,
                                     const float* __restrict__ scale, const float* __restrict__ shift,
                                     const float* __restrict__ mean, const float* __restrict__ invstd, float slope,
                                     const double* __restrict__ red, double inv_count, long long n4, int N) {
   const long long stride = (long long)gridDim.x * blockDim.x;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (HOIST) {                              // N divides 1024: per-channel constants in registers (see affine_act_kernel)
+    const int c = (int)((threadIdx.x * 4u) % (unsigned)N);
+    const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+    const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+    float m1[4], m2[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      m1[k] = (float)(red[2 * (c + k)] * inv_count);
+      m2[k] = (float)(red[2 * (c + k) + 1] * inv_count);
+    }
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w};
+    const f32x4* Zv = (const f32x4*)Z;
+    const f32x4* Gv = (const f32x4*)dA;
+    f32x4* Ov = (f32x4*)dZ;
+    auto one = [&](const f32x4 z, const f32x4 g) {
+      f32x4 o;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float y = z[k] * scv[k] + shv[k];
+        const float d = y > 0.f ? g[k] : g[k] * slope;
+        const float xh = (z[k] - muv[k]) * isv[k];
+        o[k] = scv[k] * (d - m1[k] - xh * m2[k]);
+      }
+      return o;
+    };
+    for (; i + stride < n4; i += 2 * stride) {
+      const f32x4 z0 = __builtin_nontemporal_load(Zv + i), z1 = __builtin_nontemporal_load(Zv + i + stride);
+      const f32x4 g0 = __builtin_nontemporal_load(Gv + i), g1 = __builtin_nontemporal_load(Gv + i + stride);
+      __builtin_nontemporal_store(one(z0, g0), Ov + i);
+      __builtin_nontemporal_store(one(z1, g1), Ov + i + stride);
+    }
+    for (; i < n4; i += stride) Ov[i] = one(Zv[i], Gv[i]);
+    return;
+  }
+  for (; i < n4; i += stride) {
     const int c = (int)((i * 4) % N);
     const float4 z = ((const float4*)Z)[i], g = ((const float4*)dA)[i];
     const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
@@ -154,9 +238,12 @@ __global__ void act_bwd_kernel(const float* __restrict__ Z, const float* __restr
   }
 }
 
+// grid of a grid-stride streaming kernel.  Measured with tools/probe/copy_probe.hip on a 5.67 GB tensor: 4096 blocks
+// 5.8 TB/s, 16384 blocks 6.3 TB/s, 65536 blocks 6.6 TB/s (1R+1W, 4 x 16 B in flight per thread, nontemporal): many
+// short blocks balance the 8 XCDs better than a persistent-sized grid.
 inline unsigned stream_grid(long long work_items) {
-  long long b = cy_ceil_div(work_items, 256);
-  if (b > 256 * 16) b = 256 * 16;
+  long long b = cy_ceil_div(work_items, 256 * 4);
+  if (b > 65536) b = 65536;
   if (b < 1) b = 1;
   return (unsigned)b;
 }
@@ -194,8 +281,11 @@ extern "C" int cy_affine_act(const float* Z, float* A, const float* scale, const
   hipStream_t s = (hipStream_t)stream;
   const long long n = P * N;
   const bool v4 = (N % 4 == 0) && (((uintptr_t)Z & 15) == 0) && (((uintptr_t)A & 15) == 0);
-  if (v4 && scale) affine_act_kernel<true><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
-  else if (v4) affine_act_kernel<false><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  const bool hoist = v4 && N <= 1024 && (1024 % N) == 0;
+  if (hoist && scale) affine_act_kernel<true, true><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  else if (hoist) affine_act_kernel<false, true><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  else if (v4 && scale) affine_act_kernel<true, false><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
+  else if (v4) affine_act_kernel<false, false><<<stream_grid(n / 4), 256, 0, s>>>(Z, A, scale, shift, slope, n / 4, N);
   else affine_act_scalar_kernel<<<stream_grid(n), 256, 0, s>>>(Z, A, scale, shift, slope, n, N);
   CY_LAUNCH_CHECK("cy_affine_act");
   return 0;
@@ -228,8 +318,12 @@ extern "C" int cy_bn_bwd_apply(const float* Z, const float* dA, float* dZ, const
   (void)gamma;
   hipStream_t s = (hipStream_t)stream;
   const long long n4 = P * N / 4;
-  bn_bwd_apply_kernel<<<stream_grid(n4), 256, 0, s>>>(Z, dA, dZ, scale, shift, mean, invstd, slope, red,
-                                                      1.0 / (double)P, n4, N);
+  if (N <= 1024 && (1024 % N) == 0)
+    bn_bwd_apply_kernel<true><<<stream_grid(n4), 256, 0, s>>>(Z, dA, dZ, scale, shift, mean, invstd, slope, red,
+                                                              1.0 / (double)P, n4, N);
+  else
+    bn_bwd_apply_kernel<false><<<stream_grid(n4), 256, 0, s>>>(Z, dA, dZ, scale, shift, mean, invstd, slope, red,
+                                                               1.0 / (double)P, n4, N);
   CY_LAUNCH_CHECK("cy_bn_bwd_apply");
   if (dgamma && dbeta) {
     bn_param_grad_kernel<<<(N + 255) / 256, 256, 0, s>>>(red, dgamma, dbeta, N);

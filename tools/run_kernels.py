@@ -50,6 +50,22 @@ if what in ('conv3', 'all'):
     timeit('conv3 dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, 256), 4, 2, 1), fl)
     timeit('conv3 wgrad', lambda: ops.conv_wgrad(x, dz, 4, 2, 1), fl)
     del x, dz
+if what in ('bn', 'all'):
+    from capsyolo_amd._lib import call
+    H, N = 416, 256
+    P = B * H * H
+    z = torch.randn(P, N, device=dev)
+    da = torch.randn(P, N, device=dev)
+    out = torch.empty_like(z)
+    sc, sh = torch.rand(N, device=dev) + 0.5, torch.randn(N, device=dev)
+    mu, isd = torch.randn(N, device=dev) * 0.1, torch.rand(N, device=dev) + 0.5
+    red = torch.zeros(N, 2, dtype=torch.float64, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = z.numel() * 4.0
+    timeit('affine_act (BN apply + LeakyReLU)', lambda: call('cy_affine_act', z.data_ptr(), out.data_ptr(), sc.data_ptr(), sh.data_ptr(), 0.1, P, N, st), None, 2 * nb)
+    timeit('bn_bwd_reduce', lambda: call('cy_bn_bwd_reduce', z.data_ptr(), da.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 0.1, red.data_ptr(), P, N, st), None, 2 * nb)
+    timeit('bn_bwd_apply', lambda: call('cy_bn_bwd_apply', z.data_ptr(), da.data_ptr(), out.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), None, 0.1, red.data_ptr(), None, None, P, N, st), None, 3 * nb)
+    del z, da, out
 if what in ('routing', 'all'):
     g = 13
     feat = torch.randn(B, 4 * g, 4 * g, 256, device=dev, requires_grad=True)
