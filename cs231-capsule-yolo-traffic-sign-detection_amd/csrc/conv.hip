@@ -224,28 +224,50 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
 #undef CY_LOAD_A_VEC
 #undef CY_LOAD_A_SCALAR
 
-  // ---- epilogue: bias, activation, store, optional BatchNorm statistics
+  // ---- epilogue: bias, activation, store, optional BatchNorm statistics.
+  // The wave's 64 x (32 NTW) tile goes through its own slice of the (now idle) operand LDS so that the global stores
+  // are 16 bytes per lane and 128-256 contiguous bytes per pixel row: 16 (8) store instructions per lane instead of
+  // 64 (32) four-byte ones (conv_1, whose launch is nothing but its 2.8 GB of output, ran at 1.3 TB/s before).
+  constexpr int WC = 32 * NTW;             // columns of the wave tile
+  float* ow = smem + wave * (64 * WC);     // [64 rows][WC]; all waves are past the K loop's last barrier
   float ssum[NTW], ssq[NTW];
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
     ssum[ni] = 0.f; ssq[ni] = 0.f;
-    const int n = n0 + wave_n * 32 * NTW + ni * 32 + li;
+    const int n = n0 + wave_n * WC + ni * 32 + li;
     const float bv = (a.bias != nullptr && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = wave_m * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const long long off = rowoff[row];
+        const int row_l = mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         float v = acc[mi][ni][r] + bv;
-        if (off >= 0 && n < a.N) {
-          ssum[ni] += v; ssq[ni] += v * v;
-          if (a.act == 1) v = fmaxf(v, 0.f);
-          a.Y[off + n] = v;
+        if (a.stats != nullptr && n < a.N && rowoff[wave_m * 64 + row_l] >= 0) { ssum[ni] += v; ssq[ni] += v * v; }
+        if (a.act == 1) v = fmaxf(v, 0.f);
+        ow[row_l * WC + ni * 32 + li] = v;
+      }
+    }
+  }
+  {
+    constexpr int LPR = WC / 4, RPI = 64 / LPR;          // lanes per row, rows per store instruction
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    const int n = n0 + wave_n * WC + c4 * 4;
+    const bool vec_ok = (a.N & 3) == 0 && (((uintptr_t)a.Y & 15) == 0);
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row_l = it * RPI + rsub;
+      const long long off = rowoff[wave_m * 64 + row_l];
+      const f32x4 v = *(const f32x4*)(ow + row_l * WC + c4 * 4);
+      if (off >= 0) {
+        if (vec_ok && n + 3 < a.N) *(f32x4*)(a.Y + off + n) = v;
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (n + k < a.N) a.Y[off + n + k] = v[k];
         }
       }
     }
   }
+  __syncthreads();                         // the statistics reduction below reuses the same LDS
   if (a.stats != nullptr) {
     float* red = smem;                     // reuse the A image: [2 wave_m][BN][2]
 #pragma unroll
