@@ -12,8 +12,13 @@ __global__ void bn_finalize_kernel(const double* __restrict__ stats, double coun
                                    float* invstd, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  const double m = stats[2 * n] / count;
-  double var = stats[2 * n + 1] / count - m * m;           // biased variance normalises the batch
+  double s1 = 0.0, s2 = 0.0;
+  for (int cp = 0; cp < CY_STATS_COPIES; ++cp) {            // fixed order: deterministic given the copies
+    s1 += stats[((size_t)cp * N + n) * 2];
+    s2 += stats[((size_t)cp * N + n) * 2 + 1];
+  }
+  const double m = s1 / count;
+  double var = s2 / count - m * m;                         // biased variance normalises the batch
   if (var < 0.0) var = 0.0;
   const float is = (float)(1.0 / sqrt(var + (double)eps));
   const float sc = gamma[n] * is;

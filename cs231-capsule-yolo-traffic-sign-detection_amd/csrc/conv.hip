@@ -284,8 +284,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
     if (t < BN && n0 + t < a.N) {
       double s = (double)red[t * 2] + (double)red[(BN + t) * 2];
       double q = (double)red[t * 2 + 1] + (double)red[(BN + t) * 2 + 1];
-      atomicAdd(a.stats + 2 * (n0 + t), s);
-      atomicAdd(a.stats + 2 * (n0 + t) + 1, q);
+      double* st = a.stats + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.N * 2;
+      atomicAdd(st + 2 * (n0 + t), s);
+      atomicAdd(st + 2 * (n0 + t) + 1, q);
     }
   }
 }

@@ -450,8 +450,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       }
       __syncthreads();
       if (t < WN && nb * WN + t < a.Cout) {
-        atomicAdd(a.stats + 2 * (nb * WN + t), (double)red[t * 2] + (double)red[(WN + t) * 2]);
-        atomicAdd(a.stats + 2 * (nb * WN + t) + 1, (double)red[t * 2 + 1] + (double)red[(WN + t) * 2 + 1]);
+        double* st = a.stats + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.Cout * 2;
+        atomicAdd(st + 2 * (nb * WN + t), (double)red[t * 2] + (double)red[(WN + t) * 2]);
+        atomicAdd(st + 2 * (nb * WN + t) + 1, (double)red[t * 2 + 1] + (double)red[(WN + t) * 2 + 1]);
       }
     }
 

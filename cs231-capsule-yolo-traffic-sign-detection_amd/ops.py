@@ -78,6 +78,7 @@ def _x_geometry(x, nchw):
     return B, Hi, Wi, Cin, (Hi * Wi * Cin, Wi * Cin, Cin, 1)
 
 
+STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 
 
@@ -223,7 +224,7 @@ class _ConvBlock(torch.autograd.Function):
         scale, shift = _empty((N,), x), _empty((N,), x)
         mean, invstd = _empty((N,), x), _empty((N,), x)
         if bn.training:
-            stats = torch.zeros((N, 2), dtype=torch.float64, device=x.device)
+            stats = torch.zeros((STATS_COPIES, N, 2), dtype=torch.float64, device=x.device)
             z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name)
             P = z.numel() // N
             call('cy_bn_finalize', _ptr(stats), P, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),

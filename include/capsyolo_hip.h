@@ -55,8 +55,11 @@ long long cy_conv_packed_floats(int K, int N);
  * input-gradient operand (rows = (tap, cout), columns = cin). */
 int cy_conv_pack_weights(const float* W, float* Wp, int Cout, int Cin, int KH, int KW,
                          int TH, int TW, int kh0, int kw0, int kstep, int transpose, void* stream);
-/* Y = conv(X) (+bias, +act); if stats != NULL also accumulates per-channel sum / sum-of-squares
- * of the pre-activation output into stats[N][2] (double), which the caller zeroed. */
+/* Y = conv(X) (+bias, +act); if stats != NULL also accumulates per-channel sum / sum-of-squares of the
+ * pre-activation output into stats[CY_STATS_COPIES][N][2] (double), which the caller zeroed: every block adds into
+ * copy (block id mod CY_STATS_COPIES), so that tens of thousands of blocks do not queue on 2 N addresses (conv_1's
+ * launch was bound by exactly that); cy_bn_finalize adds the copies up. */
+#define CY_STATS_COPIES 16
 int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream);
 
 /* weight gradient: dW[Cout][Cin][KH][KW] = sum over pixels of X-patch (x) dZ.
@@ -92,7 +95,7 @@ int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream
 
 /* ------------------------------------------------------------------ BatchNorm2d (+LeakyReLU), NHWC
  * Replaces nn.BatchNorm2d + nn.LeakyReLU in training and eval mode (models.py:132-223, 347-365). */
-/* stats[N][2] (sum, sumsq from cy_conv_gemm) -> scale/shift (gamma*invstd, beta-mean*scale),
+/* stats[CY_STATS_COPIES][N][2] (sum, sumsq from cy_conv_gemm / cy_conv3x3_winograd) -> scale/shift (gamma*invstd, beta-mean*scale),
  * mean, invstd; updates running_mean/var with `momentum` (unbiased variance), as torch does. */
 int cy_bn_finalize(const double* stats, long long count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, float momentum, float eps,

@@ -81,8 +81,9 @@ def test_conv3x3_winograd_matches_direct_and_fp64(case):
     xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
     gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
     assert ops.USE_WINOGRAD
-    stats = torch.zeros((Cout, 2), dtype=torch.float64, device=dev())
+    stats = torch.zeros((ops.STATS_COPIES, Cout, 2), dtype=torch.float64, device=dev())
     z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1, False, stats)
+    stats = stats.sum(0)
     dx = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), 3, 1, 1)
     close(z.permute(0, 3, 1, 2), zr, 5e-5, 5e-5)
     close(dx.permute(0, 3, 1, 2), xd.grad, 1e-4, 1e-4)
@@ -138,8 +139,9 @@ def test_conv_relu_epilogue_and_stats():
     b = rnd((128,), 7, 0.1)
     zr = F.conv2d(x.double(), w.double(), b.double(), padding=1)
     xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
-    stats = torch.zeros((128, 2), dtype=torch.float64, device=dev())
+    stats = torch.zeros((ops.STATS_COPIES, 128, 2), dtype=torch.float64, device=dev())
     z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 3, 1, 1, False, stats, False)
+    stats = stats.sum(0)
     close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
     close(stats[:, 0], zr.sum(dim=(0, 2, 3)), 1e-5, 1e-5)
     close(stats[:, 1], (zr ** 2).sum(dim=(0, 2, 3)), 1e-5, 1e-5)

@@ -35,7 +35,7 @@ if what in ('conv2', 'all'):
     b = torch.zeros(256, device=dev)
     dz = torch.randn(B, H, H, 256, device=dev)
     fl = 2.0 * B * H * H * 256 * 1152
-    stats = torch.zeros(256, 2, dtype=torch.float64, device=dev)
+    stats = torch.zeros(ops.STATS_COPIES, 256, 2, dtype=torch.float64, device=dev)
     timeit('conv2 fwd (+stats)', lambda: ops.conv_forward(x, w, b, 3, 1, 1, False, stats, False), fl)
     timeit('conv2 dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, 128), 3, 1, 1), fl)
     timeit('conv2 wgrad', lambda: ops.conv_wgrad(x, dz, 3, 1, 1), fl)
