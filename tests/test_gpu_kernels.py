@@ -65,7 +65,8 @@ def test_conv_fwd_dgrad_wgrad(case):
         close(dx.permute(0, 3, 1, 2), xd.grad, 5e-5, 5e-5)
 
 
-@pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10)])
+@pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10),
+                                  (3, 8, 200, 64), (2, 16, 104, 128)])   # > 256 tiles: persistent blocks walk several tiles
 def test_conv3x3_winograd_matches_direct_and_fp64(case):
     """Fused Winograd F(2x2,3x3) (forward + input gradient, bias, BN statistics, odd sizes, padded channels)
     against torch fp64, and switched off against the direct implicit GEMM."""
