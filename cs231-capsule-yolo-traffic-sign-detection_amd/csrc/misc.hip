@@ -28,6 +28,63 @@ __global__ void center_u8_kernel(const unsigned char* __restrict__ src, float* _
   }
 }
 
+// y_to_boxes_vec (utils.py:288-334) on the device: boxes whose confidence exceeds the threshold, in np.argwhere order
+// (image, row, col, box), de-normalised to pixels (utils.py:233-252) and converted to corners (utils.py:254-269),
+// class = first arg-max of the cell's class scores.  One block: the candidates (B g g nb, 10 816 at B=32 / g=13) are
+// swept in chunks of 1024 with an order-preserving block scan.  Arithmetic in double, like the reference's numpy.
+__global__ __launch_bounds__(1024) void yolo_decode_kernel(const float* __restrict__ y, const long long* __restrict__ image_hw,
+                                                           double img_h, double img_w, int B, int g, int nb, int C, float conf_th,
+                                                           int* count, int* image_idx, double* xy, int* cls, int max_boxes) {
+  __shared__ int wave_cnt[16];
+  __shared__ int base_s;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int D = 5 * nb + C;
+  const long long total = (long long)B * g * g * nb;
+  if (t == 0) base_s = 0;
+  __syncthreads();
+  for (long long c0 = 0; c0 < total; c0 += 1024) {
+    const long long i = c0 + t;
+    bool hit = false;
+    int bi = 0, row = 0, col = 0, k = 0;
+    if (i < total) {
+      long long r = i;
+      k = (int)(r % nb); r /= nb;
+      col = (int)(r % g); r /= g;
+      row = (int)(r % g); bi = (int)(r / g);
+      hit = y[(((long long)bi * g + row) * g + col) * D + 5 * k] > conf_th;
+    }
+    const unsigned long long m = __ballot(hit);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
+    int before = 0, chunk_total = 0;
+    for (int w = 0; w < 16; ++w) { const int cnt = wave_cnt[w]; if (w < wave) before += cnt; chunk_total += cnt; }
+    const int base = base_s;
+    if (hit) {
+      const int o = base + before + __popcll(m & ((1ull << lane) - 1ull));
+      if (o < max_boxes) {
+        const float* cell = y + (((long long)bi * g + row) * g + col) * D;
+        const double ih = image_hw ? (double)image_hw[2 * bi] : img_h, iw = image_hw ? (double)image_hw[2 * bi + 1] : img_w;
+        const double gw = 1.0 * iw / g, gh = 1.0 * ih / g;
+        double xc = (double)cell[5 * k + 1] * gw, yc = (double)cell[5 * k + 2] * gh;
+        const double w_ = (double)cell[5 * k + 3] * iw, h_ = (double)cell[5 * k + 4] * ih;
+        xc += col * gw; yc += row * gh;
+        image_idx[o] = bi;
+        xy[4 * o + 0] = xc - w_ / 2; xy[4 * o + 1] = yc - h_ / 2;
+        xy[4 * o + 2] = xc + w_ / 2; xy[4 * o + 3] = yc + h_ / 2;
+        if (C > 0) {
+          int best = 0; float bv = cell[5 * nb];
+          for (int c = 1; c < C; ++c) { const float v = cell[5 * nb + c]; if (v > bv) { bv = v; best = c; } }
+          cls[o] = best;
+        }
+      }
+    }
+    __syncthreads();
+    if (t == 0) base_s = base + chunk_total;
+    __syncthreads();
+  }
+  if (t == 0) *count = base_s;
+}
+
 // generic 4-D permute: out[b][i1][i2][i3] (contiguous) = in[b*sb + i1*s1 + i2*s2 + i3*s3]
 __global__ void permute4_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int d1, int d2, int d3,
                                 long long sb, long long s1, long long s2, long long s3, int scatter) {
@@ -161,6 +218,15 @@ extern "C" int cy_center_u8(const unsigned char* src, float* dst, int B, int H, 
   const long long npix = (long long)B * H * W;
   center_u8_kernel<<<grid_for(npix * C), 256, 0, CY_S>>>(src, dst, npix, C, (long long)H * W, to_nchw);
   CY_LAUNCH_CHECK("cy_center_u8");
+  return 0;
+}
+extern "C" int cy_yolo_decode_boxes(const float* y, const long long* image_hw, double img_h, double img_w, int B, int g, int nb,
+                                    int C, float conf_th, int* count, int* image_idx, double* xy, int* cls, int max_boxes,
+                                    void* stream) {
+  CY_REQUIRE(y && count && image_idx && xy && B > 0 && g > 0 && nb > 0 && C >= 0 && max_boxes > 0, "cy_yolo_decode_boxes: bad arguments");
+  CY_REQUIRE(C == 0 || cls, "cy_yolo_decode_boxes: cls must be given when C > 0");
+  yolo_decode_kernel<<<1, 1024, 0, CY_S>>>(y, image_hw, img_h, img_w, B, g, nb, C, conf_th, count, image_idx, xy, cls, max_boxes);
+  CY_LAUNCH_CHECK("cy_yolo_decode_boxes");
   return 0;
 }
 extern "C" int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,

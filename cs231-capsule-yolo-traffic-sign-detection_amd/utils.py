@@ -73,3 +73,30 @@ def shuffle(x, y):
     """utils.py:146-148."""
     i = np.random.permutation(len(y))
     return x[i], y[i]
+
+
+def y_to_boxes_vec(y, params, image_hw=None, conf_th=0.5):
+    """utils.py:288-334 on the device (`cy_yolo_decode_boxes`): y is the network output / ground truth as a numpy
+    array or a tensor, image_hw an optional (batch, 2) array of (height, width).  Returns (image_indices, xy, classes)
+    as numpy arrays like the reference (classes is None when params.n_classes == 0)."""
+    from ._lib import call
+    yt = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device='cuda', dtype=torch.float32).contiguous()
+    batch, g, _, D = yt.shape
+    C = int(params.n_classes)
+    nb = int((D - C) / 5)
+    cap = batch * g * g * nb
+    dev = yt.device
+    count = torch.zeros(1, dtype=torch.int32, device=dev)
+    idx = torch.empty(cap, dtype=torch.int32, device=dev)
+    xy = torch.empty((cap, 4), dtype=torch.float64, device=dev)
+    cls = torch.empty(cap, dtype=torch.int32, device=dev) if C else None
+    hw = None
+    if image_hw is not None:
+        hw = torch.as_tensor(np.ascontiguousarray(np.asarray(image_hw).reshape(batch, 2)), dtype=torch.int64).to(dev)
+    side = float(params.darknet_input)
+    call('cy_yolo_decode_boxes', yt.data_ptr(), hw.data_ptr() if hw is not None else None, side, side, batch, g, nb, C,
+         float(conf_th), count.data_ptr(), idx.data_ptr(), xy.data_ptr(), cls.data_ptr() if C else None, cap,
+         torch.cuda.current_stream().cuda_stream)
+    n = int(count.item())
+    return (idx[:n].cpu().numpy().astype(np.int64), xy[:n].cpu().numpy(),
+            cls[:n].cpu().numpy().astype(np.int64) if C else None)

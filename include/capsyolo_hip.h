@@ -192,6 +192,13 @@ int cy_tanh_bwd(const float* y, const float* dy, float* dx, long long n, void* s
 /* DarkNet head (models.py:226-236): sigmoid on the first `split` values of each cell, softmax on the other C */
 int cy_yolo_head_fwd(const float* x, float* y, long long cells, int split, int C, void* stream);
 int cy_yolo_head_bwd(const float* y, const float* dy, float* dx, long long cells, int split, int C, void* stream);
+/* Eval / predict side: utils.y_to_boxes_vec (utils.py:288-334 with 233-269) on the device.
+ * y [B][g][g][5 nb + C] network output (or ground truth, nb = 1); boxes with confidence > conf_th come out in
+ * np.argwhere order: image_idx[n], xy[n][4] = (x1, y1, x2, y2) in pixels (double, the reference's numpy precision),
+ * cls[n] (only if C > 0).  image_hw: [B][2] int64 (height, width) per image, or NULL for img_h x img_w everywhere.
+ * *count = number of boxes found (may exceed max_boxes: only the first max_boxes are written). */
+int cy_yolo_decode_boxes(const float* y, const long long* image_hw, double img_h, double img_w, int B, int g, int nb, int C,
+                         float conf_th, int* count, int* image_idx, double* xy, int* cls, int max_boxes, void* stream);
 /* torch.gather of the labelled capsule (models.py:122): backward=0: out[B][D] = caps[b][y[b]][:];
  * backward=1: caps is d(out) [B][D], out = d(caps) [B][C][D] (zero off the labelled capsule) */
 int cy_pick_capsule(const float* caps, const long long* y, float* out, int B, int C, int D, int backward, void* stream);

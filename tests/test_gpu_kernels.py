@@ -391,3 +391,27 @@ def test_center_u8_and_device_feeder_match_reference_expression():
             want = torch.from_numpy(np.ascontiguousarray(xf)).float().permute(0, 3, 1, 2).contiguous()
             assert xa.dtype == torch.float32 and torch.equal(xa.cpu(), want)
             assert torch.equal(ya.cpu(), torch.from_numpy(yb))
+
+
+@pytest.mark.parametrize('tag', ['det', 'rec', 'sq', 'none'])
+def test_y_to_boxes_vec_device_matches_reference(tag):
+    """cy_yolo_decode_boxes against the reference's utils.y_to_boxes_vec outputs (order, pixels in double, classes)."""
+    import types
+    from capsyolo_amd import utils
+    from helpers import load_golden
+    gold = load_golden('boxes')
+    seed, B, g, nb, C, use_hw, th = [int(v) for v in gold[tag + '_cfg']]
+    rng = np.random.default_rng(seed)
+    y = rng.random((B, g, g, 5 * nb + C)).astype(np.float32)
+    y[..., 0:5 * nb:5] *= 0.7
+    hw = rng.integers(200, 900, (B, 2)).astype(np.int64)
+    if tag == 'none':
+        y[..., 0::5] = 0.1
+    p = types.SimpleNamespace(n_classes=C, darknet_input=416)
+    idx, xy, cls = utils.y_to_boxes_vec(y, p, image_hw=hw if use_hw else None, conf_th=th / 1000.0)
+    assert np.array_equal(idx, gold[tag + '_idx'])
+    np.testing.assert_allclose(xy, gold[tag + '_xy'].reshape(-1, 4), rtol=1e-14, atol=1e-11)
+    if C:
+        assert np.array_equal(cls, gold[tag + '_cls'])
+    else:
+        assert cls is None

@@ -252,3 +252,29 @@ def test_state_dict_keys_match_reference_names():
     for k in ('model.conv_1.weight', 'model.bn_18.running_mean', 'model.conv_19.weight'):
         assert k in keys
     assert 'model.conv_1.bias' not in keys
+
+
+def _boxes_case(seed, B, g, nb, C):
+    rng = np.random.default_rng(seed)
+    y = rng.random((B, g, g, 5 * nb + C)).astype(np.float32)
+    y[..., 0:5 * nb:5] *= 0.7
+    hw = rng.integers(200, 900, (B, 2)).astype(np.int64)
+    return y, hw
+
+
+@pytest.mark.parametrize('tag', ['det', 'rec', 'sq', 'none'])
+def test_y_to_boxes_vec_oracle_matches_reference(tag):
+    """oracle/utils_np.y_to_boxes_vec against outputs of the reference's utils.y_to_boxes_vec (utils.py:288-334)."""
+    from oracle import utils_np
+    gold = load_golden('boxes')
+    seed, B, g, nb, C, use_hw, th = [int(v) for v in gold[tag + '_cfg']]
+    y, hw = _boxes_case(seed, B, g, nb, C)
+    if tag == 'none':
+        y[..., 0::5] = 0.1
+    idx, xy, cls = utils_np.y_to_boxes_vec(y, C, 416, image_hw=hw if use_hw else None, conf_th=th / 1000.0)
+    assert np.array_equal(idx, gold[tag + '_idx'])
+    assert np.array_equal(xy, gold[tag + '_xy'])
+    if C:
+        assert np.array_equal(cls, gold[tag + '_cls'])
+    else:
+        assert cls is None
