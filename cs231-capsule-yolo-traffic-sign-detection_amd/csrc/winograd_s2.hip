@@ -1,0 +1,427 @@
+// Fused Winograd F(2x2, 2x2) forward for 4x4 / stride 2 / pad 1 convolutions on NHWC fp32 (DarkCapsuleNet conv_3..5,
+// models.py:352-363: 24 % of the step), gfx950.
+//
+// A 4x4 stride-2 pad-1 convolution is a 2x2 stride-1 convolution of the space-to-depth view shifted by one pixel,
+//   X'(Y, X, (py, px, c)) = in(2Y - 1 + py, 2X - 1 + px, c)      (zero outside the image),
+//   out(y, x, co) = sum_{a,b in {0,1}} sum_q X'(y + a, x + b, q) g'(co, q, a, b),   g'(co,(py,px,c),a,b) = w[co][c][2a+py][2b+px],
+// and a 2x2 kernel has the minimal-filtering form F(2x2, 2x2): 9 multiplies per 2x2 outputs instead of 16,
+//   Y = A^T [(G g' G^T) (.) (B^T d B)] A,  B^T = [[1,-1,0],[0,1,0],[0,-1,1]], G = [[1,0],[1,1],[0,1]], A^T = [[1,1,0],[0,1,1]]
+// (only +-1 coefficients: no rounding beyond the additions).  The kernel never materialises X': a chunk of the
+// reduction is one (py, px) and 8 input channels, its 17x33 patch of X' is a stride-2 sampling of the input.
+//
+// Structure = winograd.hip's forward kernel (see the comments there for the measured cost model): one block = 8 x 16
+// tiles (16 x 32 output pixels) x 64 output channels, 4 waves (2 x 2), ONE wave per SIMD; wave (wm, wn) owns 64
+// tiles x 32 channels x 9 positions = 18 accumulator tiles (288 registers); per chunk 72 MFMAs per wave, every other
+// piece of work (U / patch global loads, LDS stores, the input transform on channel pairs with v_pk_add_f32) in one
+// of the 72 slots between them.  9 global loads per 72 MFMAs (the 3x3 kernel has 11 per 64).
+#include "common.h"
+
+namespace {
+
+constexpr int TR2 = 8, TC2 = 16;            // tile rows / columns per block
+constexpr int NT2 = TR2 * TC2;              // 128 tiles
+constexpr int PR2 = 2 * TR2 + 1, PC2 = 2 * TC2 + 1;   // 17 x 33 patch of X'
+constexpr int NPIX2 = PR2 * PC2;            // 561
+constexpr int RAWP2 = 577;                  // >= 561, = 1 (mod 16): the k-quad stride is 4 banks (mod 64)
+constexpr int RAW2_BUF = 2 * RAWP2 * 4;     // floats: [kq][pixel][4]
+constexpr int SLABV = NT2 * 4 + 4;          // floats per (xi, kq) slab of V
+constexpr int SLABU = 64 * 4 + 4;           // floats per (xi, kq) slab of U
+constexpr int V2_BUF = 18 * SLABV, U2_BUF = 18 * SLABU;
+constexpr int NRAWQ = 5, NUQ = 5;           // float4 items per thread: 1122 patch items, 1152 U items over 256 threads
+
+struct Wino2Args {
+  const float* X; const float* U; float* Y; const float* bias; double* stats;
+  int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ float acc_elem(float a_elem) {   // one accumulator element, read where the statement stands
+  float x;
+  asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem));
+  return x;
+}
+
+// ---- compile-time schedule of one chunk: 72 slots; slot s issues the MFMA of position s / 8, row tile s & 1,
+// k-step (s >> 1) & 3 (consecutive MFMAs alternate between the position's two accumulators).  Position xi + 1's three
+// fragments (A0, A1, B) are fetched in the first three slots of position xi.
+constexpr int S2_SU[2] = {3, 4};
+constexpr int S2_SRAW[5] = {5, 6, 7, 11, 12};
+constexpr int S2_GRAW[5] = {13, 15, 20, 22, 27};
+constexpr int S2_GU[5] = {14, 19, 21, 23, 28};
+constexpr int S2_TRD[9] = {29, 30, 31, 35, 36, 37, 38, 39, 43};
+constexpr int S2_TV[6] = {44, 45, 46, 47, 51, 52};
+constexpr int s2_find(const int* list, int n, int s) {
+  for (int i = 0; i < n; ++i) if (list[i] == s) return i;
+  return -1;
+}
+// kinds: 1 S_U (LDS writes of U(c+1): 3 + 2)  7 S_raw (one float4 of patch c+2)  2 G_raw (one load of patch c+3)
+//        3 G_U (one load of U c+2)  4 T_rd (two float2 of patch c+1)  5 T_v (one row of V for one of the two items)
+constexpr int s2_kind(int s) {
+  return s2_find(S2_SU, 2, s) >= 0 ? 1 : s2_find(S2_SRAW, 5, s) >= 0 ? 7 : s2_find(S2_GRAW, 5, s) >= 0 ? 2
+       : s2_find(S2_GU, 5, s) >= 0 ? 3 : s2_find(S2_TRD, 9, s) >= 0 ? 4 : s2_find(S2_TV, 6, s) >= 0 ? 5 : 0;
+}
+constexpr int s2_idx(int s) {
+  const int k = s2_kind(s);
+  return k == 1 ? s2_find(S2_SU, 2, s) : k == 7 ? s2_find(S2_SRAW, 5, s) : k == 2 ? s2_find(S2_GRAW, 5, s)
+       : k == 3 ? s2_find(S2_GU, 5, s) : k == 4 ? s2_find(S2_TRD, 9, s) : k == 5 ? s2_find(S2_TV, 6, s) : 0;
+}
+// LOWER bound of the LDS instructions a slot's side work issues (two float2 reads may merge into one ds_read2_b64;
+// exec-masked stores may be skipped by a whole wave)
+constexpr int s2_side_lds(int s) {
+  const int k = s2_kind(s), i = s2_idx(s);
+  return k == 1 ? (i == 0 ? 3 : 1) : k == 7 ? (i < 4 ? 1 : 0) : k == 4 ? 1 : k == 5 ? 3 : 0;
+}
+constexpr int s2_frag_lds(int s) { return ((s & 7) < 3 && s + 8 < 72) ? 1 : 0; }
+// LDS operations younger than position xi's last fragment (B) when its first MFMA issues
+constexpr int s2_younger(int xi) {
+  if (xi == 0) return 0;
+  int n = s2_side_lds(8 * (xi - 1) + 2);
+  for (int s = 8 * (xi - 1) + 3; s < 8 * xi; ++s) n += s2_frag_lds(s) + s2_side_lds(s);
+  return n > 14 ? 14 : n;
+}
+
+__global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                         // [2][V2_BUF]
+  float* Us = smem + 2 * V2_BUF;            // [2][U2_BUF]
+  float* Rs = smem + 2 * V2_BUF + 2 * U2_BUF;   // [2][RAW2_BUF]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 31, lh = lane >> 5;
+
+  unsigned vid = blockIdx.x;                // XCD-aware ids: the Np/64 blocks of one patch share an L2 (winograd.hip)
+  if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int nblk = a.Np / 64;
+  const int nb = vid % nblk;
+  int rest = vid / nblk;
+  const int tbx = rest % a.tbw; rest /= a.tbw;
+  const int tby = rest % a.tbh;
+  const int b = rest / a.tbh;
+  const int Y0 = tby * (2 * TR2), X0 = tbx * (2 * TC2);      // first output row / column = first X' row / column
+  const int cpp = a.Cin / 8;                // chunks per (py, px)
+  const int nchunk = 4 * cpp;
+
+  // ---- patch loader: item = t + 256 q -> 16 pixels x 2 k-quads per 32 items (conflict-free b128 LDS stores, both
+  // 16-byte halves of a pixel's 32 bytes in one wave-load)
+  int roff[NRAWQ]; int iy00[NRAWQ], ix00[NRAWQ]; bool rvalid[NRAWQ];
+  unsigned gvoff[NRAWQ];                    // byte offset of (py, px) = (0, 0), channel 0 from the image base (fast path)
+  const bool blk_fast = Y0 >= 1 && X0 >= 1 && 2 * (Y0 + PR2 - 1) + 1 <= a.H - 1 && 2 * (X0 + PC2 - 1) + 1 <= a.W - 1;   // uniform
+  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);
+#pragma unroll
+  for (int q = 0; q < NRAWQ; ++q) {
+    const int item = t + 256 * q;
+    const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
+    rvalid[q] = pix < NPIX2;
+    const int pr = pix / PC2, pc = pix - pr * PC2;
+    iy00[q] = 2 * (Y0 + pr) - 1; ix00[q] = 2 * (X0 + pc) - 1;
+    roff[q] = rvalid[q] ? (kq * RAWP2 + pix) * 4 : -1;
+    gvoff[q] = (blk_fast && rvalid[q]) ? (unsigned)(((iy00[q] * a.W + ix00[q]) * a.Cin + kq * 4) * 4) : 0u;
+  }
+  const int kq_of_thread = (t >> 4) & 1;    // k-quad of every item of this thread (256 q keeps bit 4)
+  // ---- U loader: 18 segments (xi * 2 + kq) of 64 channels x float4 per chunk
+  const long long uchunk = (long long)18 * a.Np * 4;           // floats per chunk
+  int useg_ok[NUQ]; unsigned uvoff[NUQ]; int uoff[NUQ];
+#pragma unroll
+  for (int q = 0; q < NUQ; ++q) {
+    const int item = t + 256 * q;
+    const int seg = item >> 6, co = item & 63;
+    useg_ok[q] = seg < 18;
+    uvoff[q] = (unsigned)((((useg_ok[q] ? seg : 0) * a.Np) + nb * 64 + co) * 16);
+    uoff[q] = (useg_ok[q] ? seg : 0) * SLABU + co * 4;
+  }
+  // ---- transform items: channel pair tch = t & 1 of k-quad tkq, tile column (t >> 2) & 15, tile rows t >> 6 and + 4
+  const int tch = t & 1, tkq = (t >> 1) & 1, ttx = (t >> 2) & 15, tty = t >> 6;
+  const int tbase = (tkq * RAWP2 + (2 * tty) * PC2 + 2 * ttx) * 4 + 2 * tch;     // item 1: + 8 * PC2 * 4
+  const int vdst = tkq * SLABV + (tty * TC2 + ttx) * 4 + 2 * tch;                // item 1: + 4 * TC2 * 4; + xi * 2 * SLABV
+
+  f32x4 graw[NRAWQ], gu[NUQ];
+  unsigned okm = 0;                         // slow path: bit q = graw[q] is inside the image
+  auto chunk_pos = [&](int f, int& py, int& px, int& c0) {
+    const int ph = f / cpp;
+    py = ph >> 1; px = ph & 1; c0 = (f - ph * cpp) * 8;
+  };
+  auto Graw1 = [&](int q, int py, int px, int c0, f32x4& dst) {
+    if (blk_fast) {
+      dst = *(const f32x4*)(ximg + (size_t)(((py * a.W + px) * a.Cin + c0) * 4) + gvoff[q]);
+    } else {
+      const int iy = iy00[q] + py, ix = ix00[q] + px;
+      const bool ok = rvalid[q] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      dst = *(const f32x4*)(ximg + (ok ? (unsigned)(((iy * a.W + ix) * a.Cin + c0 + kq_of_thread * 4) * 4) : 0u));
+      okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
+    }
+  };
+  auto Sraw1 = [&](float* rb, int q, const f32x4& src) {
+    if (roff[q] < 0) return;
+    if (blk_fast) *(f32x4*)(rb + roff[q]) = src;
+    else *(f32x4*)(rb + roff[q]) = (okm >> q) & 1 ? src : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto GU1 = [&](int q, int f, f32x4& dst) {
+    dst = *(const f32x4*)((const char*)a.U + (long long)f * uchunk * 4 + uvoff[q]);
+  };
+  auto SU1 = [&](float* ub, int q, const f32x4& src) {
+    if (useg_ok[q]) *(f32x4*)(ub + uoff[q]) = src;
+  };
+  f32x2 xv[2][3][3];                        // the two 3x3 patches of this thread, two channels each
+  auto Vrow = [&](float* vb, int it, int R) {   // row R of V = B^T d B of item `it`
+    f32x2 t0[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+      t0[cc] = R == 0 ? pk_sub(xv[it][0][cc], xv[it][1][cc]) : R == 1 ? xv[it][1][cc] : pk_sub(xv[it][2][cc], xv[it][1][cc]);
+    float* v = vb + it * (4 * TC2 * 4);
+    *(f32x2*)(v + (R * 3 + 0) * 2 * SLABV) = pk_sub(t0[0], t0[1]);
+    *(f32x2*)(v + (R * 3 + 1) * 2 * SLABV) = t0[1];
+    *(f32x2*)(v + (R * 3 + 2) * 2 * SLABV) = pk_sub(t0[2], t0[1]);
+  };
+  auto Tall = [&](int buf_raw, int buf_v) {
+    const float* rb = Rs + buf_raw * RAW2_BUF + tbase;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) xv[it][r][cc] = *(const f32x2*)(rb + it * (8 * PC2 * 4) + (r * PC2 + cc) * 4);
+    float* vb = Vs + buf_v * V2_BUF + vdst;
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int R = 0; R < 3; ++R) Vrow(vb, it, R);
+  };
+
+  f32x16 acc[9][2];
+#pragma unroll
+  for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[xi][mi][r] = 0.f;
+
+  // ---- prologue.  State at the top of chunk c: V[c&1] / U[c&1] = chunk c, raw[(c+1)&1] = patch of chunk c+1,
+  // registers gu = U of chunk c+1, graw = patch of chunk c+2.
+  {
+    int py, px, c0;
+    f32x4 graw1[NRAWQ];
+    chunk_pos(0, py, px, c0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw[q]);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) GU1(q, 0, gu[q]);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs, q, graw[q]);
+    const int f1 = nchunk > 1 ? 1 : 0, f2 = nchunk > 2 ? 2 : nchunk - 1;
+    chunk_pos(f1, py, px, c0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw1[q]);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) SU1(Us, q, gu[q]);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) GU1(q, f1, gu[q]);
+    __syncthreads();
+    Tall(0, 0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs + RAW2_BUF, q, graw1[q]);
+    chunk_pos(f2, py, px, c0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw[q]);
+    __syncthreads();
+  }
+  const int fragA = lh * SLABV + (wm * 64 + li) * 4;     // + mi * 128
+  const int fragB = lh * SLABU + (wn * 32 + li) * 4;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* vb_ = Vs + (c & 1) * V2_BUF + fragA;
+    const float* ub_ = Us + (c & 1) * U2_BUF + fragB;
+    const float* rb_ = Rs + ((c + 1) & 1) * RAW2_BUF + tbase;       // T(c+1) reads ...
+    float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // ... and writes (harmless after the last chunk)
+    float* uw_ = Us + ((c + 1) & 1) * U2_BUF;                       // S_U(c+1)
+    float* rw_ = Rs + (c & 1) * RAW2_BUF;                           // S_raw(c+2) -> raw[(c+2)&1]
+    const int fu = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G_U(c+2), clamped: the tail re-loads valid data
+    const int fr = (c + 3 < nchunk) ? c + 3 : nchunk - 1;           // G_raw(c+3)
+    int rpy, rpx, rc0;
+    chunk_pos(fr, rpy, rpx, rc0);
+    f32x4 fa_[2][2], fb_[2];                // fragment sets, indexed by position & 1
+    fa_[0][0] = *(const f32x4*)(vb_);
+    fa_[0][1] = *(const f32x4*)(vb_ + 128);
+    fb_[0] = *(const f32x4*)(ub_);
+#define W2SLOT(SIDX)                                                                                \
+    {                                                                                               \
+      constexpr int sidx = (SIDX);                                                                  \
+      constexpr int xi = sidx >> 3, w_ = sidx & 7, mi = w_ & 1, e = w_ >> 1;                        \
+      if (w_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (s2_younger(xi) << 8));                      \
+      acc[xi][mi] = mfma32(fa_[xi & 1][mi][e], fb_[xi & 1][e], acc[xi][mi]);                        \
+      if (w_ < 3 && xi + 1 < 9) {                                                                   \
+        constexpr int nx = (xi + 1 < 9) ? xi + 1 : 0;                                               \
+        if (w_ == 0) fa_[nx & 1][0] = *(const f32x4*)(vb_ + nx * 2 * SLABV);                        \
+        if (w_ == 1) fa_[nx & 1][1] = *(const f32x4*)(vb_ + nx * 2 * SLABV + 128);                  \
+        if (w_ == 2) fb_[nx & 1] = *(const f32x4*)(ub_ + nx * 2 * SLABU);                           \
+      }                                                                                             \
+      constexpr int kind = s2_kind(sidx), k_ = s2_idx(sidx);                                        \
+      if (kind == 1) {                      /* U(c+1): registers -> LDS */                         \
+        if (k_ == 0) { SU1(uw_, 0, gu[0]); SU1(uw_, 1, gu[1]); SU1(uw_, 2, gu[2]); }                \
+        else { SU1(uw_, 3, gu[3]); SU1(uw_, 4, gu[4]); }                                            \
+      } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
+        Sraw1(rw_, k_ % NRAWQ, graw[k_ % NRAWQ]);                                                   \
+      } else if (kind == 2) {               /* patch load of chunk c+3 */                          \
+        Graw1(k_ % NRAWQ, rpy, rpx, rc0, graw[k_ % NRAWQ]);                                         \
+      } else if (kind == 3) {               /* weight load of chunk c+2 */                         \
+        GU1(k_ % NUQ, fu, gu[k_ % NUQ]);                                                            \
+      } else if (kind == 4) {               /* patch of chunk c+1: two float2 */                   \
+        constexpr int i0 = 2 * (k_ % 9), i1 = i0 + 1;                                               \
+        xv[i0 / 9][(i0 % 9) / 3][i0 % 3] = *(const f32x2*)(rb_ + (i0 / 9) * (8 * PC2 * 4) + (((i0 % 9) / 3) * PC2 + i0 % 3) * 4); \
+        xv[i1 / 9][(i1 % 9) / 3][i1 % 3] = *(const f32x2*)(rb_ + (i1 / 9) * (8 * PC2 * 4) + (((i1 % 9) / 3) * PC2 + i1 % 3) * 4); \
+      } else if (kind == 5) {               /* one row of V of one item */                         \
+        Vrow(vw_, (k_ % 6) / 3, (k_ % 6) % 3);                                                      \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define W2SLOT8(B) W2SLOT((B)) W2SLOT((B) + 1) W2SLOT((B) + 2) W2SLOT((B) + 3) W2SLOT((B) + 4) W2SLOT((B) + 5) W2SLOT((B) + 6) W2SLOT((B) + 7)
+    W2SLOT8(0) W2SLOT8(8) W2SLOT8(16) W2SLOT8(24) W2SLOT8(32) W2SLOT8(40) W2SLOT8(48) W2SLOT8(56) W2SLOT8(64)
+#undef W2SLOT8
+#undef W2SLOT
+    __syncthreads();                        // the only barrier of the chunk
+  }
+
+  // ---- output transform (lane-local) Y = A^T M A, A^T = [[1,1,0],[0,1,1]], one 32-tile half of the wave at a time
+  // through the wave's private 16 KiB of LDS (16-byte global stores), BatchNorm statistics from the same registers
+  const int co = nb * 64 + wn * 32 + li;
+  const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+  float ssum = 0.f, ssq = 0.f;
+  float* ow = smem + wave * 4096;           // [pixel = tile*4 + 2a + b][32 channels]
+  const bool has_stats = a.stats != nullptr;
+  const int oy0 = Y0, ox0 = X0;
+  const int c4 = lane & 7;
+  const int cbase = nb * 64 + wn * 32 + c4 * 4;
+  const bool vec_ok = (a.Cout & 3) == 0;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;       // tile within this half's 32
+      const int tl = wm * 64 + mi * 32 + tloc;                // tile within the block: row tl / 16, column tl % 16
+      float m[9];
+#pragma unroll
+      for (int xi = 0; xi < 9; ++xi) m[xi] = acc_elem(acc[xi][mi][r]);
+      const float y00 = (m[0] + m[1]) + (m[3] + m[4]) + bv, y01 = (m[1] + m[2]) + (m[4] + m[5]) + bv;
+      const float y10 = (m[3] + m[4]) + (m[6] + m[7]) + bv, y11 = (m[4] + m[5]) + (m[7] + m[8]) + bv;
+      float* op = ow + tloc * 128 + li;
+      op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
+      if (has_stats) {
+        const int oy = oy0 + 2 * (tl >> 4), ox = ox0 + 2 * (tl & 15);
+        if (co < a.Cout && oy < a.Ho && ox < a.Wo) {           // statistics over the outputs that exist
+          const bool vx = ox + 1 < a.Wo, vy = oy + 1 < a.Ho;
+          ssum += y00; ssq += y00 * y00;
+          if (vx) { ssum += y01; ssq += y01 * y01; }
+          if (vy) { ssum += y10; ssq += y10 * y10; }
+          if (vx && vy) { ssum += y11; ssq += y11 * y11; }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+      const int p = it * 8 + (lane >> 3);                     // pixel of this half: tile*4 + 2a + b
+      const int tloc = p >> 2, ab = p & 3;
+      const int tl = wm * 64 + mi * 32 + tloc;
+      const int oy = oy0 + 2 * (tl >> 4) + (ab >> 1), ox = ox0 + 2 * (tl & 15) + (ab & 1);
+      const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
+      if (oy < a.Ho && ox < a.Wo) {
+        float* yp = a.Y + (((long long)b * a.Ho + oy) * a.Wo + ox) * a.Cout + cbase;
+        if (vec_ok && cbase + 3 < a.Cout) *(f32x4*)yp = v;
+        else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) if (cbase + k < a.Cout) yp[k] = v[k];
+        }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __syncthreads();                          // the statistics reduction below reuses the LDS
+  if (has_stats) {
+    float* red = smem;                      // [2 wm][64][2]
+    ssum += __shfl_xor(ssum, 32, 64);
+    ssq += __shfl_xor(ssq, 32, 64);
+    if (lh == 0) {
+      red[(wm * 64 + wn * 32 + li) * 2 + 0] = ssum;
+      red[(wm * 64 + wn * 32 + li) * 2 + 1] = ssq;
+    }
+    __syncthreads();
+    if (t < 64 && nb * 64 + t < a.Cout) {
+      double* st = a.stats + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.Cout * 2;
+      atomicAdd(st + 2 * (nb * 64 + t), (double)red[t * 2] + (double)red[(64 + t) * 2]);
+      atomicAdd(st + 2 * (nb * 64 + t) + 1, (double)red[t * 2 + 1] + (double)red[(64 + t) * 2 + 1]);
+    }
+  }
+}
+
+// U[chunk f = (py*2+px) * Cin/8 + c/8][xi = i*3+j][kq][co (Np)][e] = (G g' G^T)[i][j] for c = (f % (Cin/8)) * 8 + kq*4 + e,
+// g'[a][b] = W[co][c][2a+py][2b+px], G = [[1,0],[1,1],[0,1]]
+__global__ void wino2_pack_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout, int Cin, int Np, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int e = (int)(idx & 3);
+  long long r = idx >> 2;
+  const int co = (int)(r % Np); r /= Np;
+  const int kq = (int)(r & 1); r >>= 1;
+  const int xi = (int)(r % 9); r /= 9;
+  const int cpp = Cin / 8;
+  const int f = (int)r, ph = f / cpp, c = (f - ph * cpp) * 8 + kq * 4 + e;
+  const int py = ph >> 1, px = ph & 1;
+  float u = 0.f;
+  if (co < Cout) {
+    float g[2][2];
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) g[aa][bb] = W[(((long long)co * Cin + c) * 4 + (2 * aa + py)) * 4 + (2 * bb + px)];
+    const int i = xi / 3, j = xi % 3;
+    const float r0 = i == 0 ? g[0][0] : i == 1 ? g[0][0] + g[1][0] : g[1][0];
+    const float r1 = i == 0 ? g[0][1] : i == 1 ? g[0][1] + g[1][1] : g[1][1];
+    u = j == 0 ? r0 : j == 1 ? r0 + r1 : r1;
+  }
+  U[idx] = u;
+}
+
+}  // namespace
+
+extern "C" long long cy_wino2_packed_floats(int Cin, int N) {
+  return (long long)(4 * (Cin / 8)) * 18 * ((N + 63) / 64 * 64) * 4;
+}
+
+extern "C" int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* stream) {
+  CY_REQUIRE(W && U && Cout > 0 && Cin > 0 && Cin % 8 == 0, "cy_wino2_pack_weights: bad arguments (Cin %% 8 == 0)");
+  const int Np = (Cout + 63) / 64 * 64;
+  const long long total = cy_wino2_packed_floats(Cin, Cout);
+  wino2_pack_kernel<<<(unsigned)cy_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(W, U, Cout, Cin, Np, total);
+  CY_LAUNCH_CHECK("cy_wino2_pack_weights");
+  return 0;
+}
+
+extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, int B, int H,
+                                     int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv4x4s2_winograd: bad arguments");
+  CY_REQUIRE(Cin % 8 == 0 && Cin >= 8, "cy_conv4x4s2_winograd: Cin=%d must be a multiple of 8", Cin);
+  CY_REQUIRE(H % 2 == 0 && W % 2 == 0, "cy_conv4x4s2_winograd: H=%d, W=%d must be even", H, W);
+  CY_REQUIRE((((uintptr_t)X | (uintptr_t)U) & 15) == 0, "cy_conv4x4s2_winograd: operands must be 16-byte aligned");
+  CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd: image too large for 32-bit offsets");
+  Wino2Args a;
+  a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.Np = (Cout + 63) / 64 * 64;
+  a.Ho = H / 2; a.Wo = W / 2;
+  a.tbh = (a.Ho + 2 * TR2 - 1) / (2 * TR2); a.tbw = (a.Wo + 2 * TC2 - 1) / (2 * TC2);
+  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / 64);
+  CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd: grid too large");
+  const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF) * 4;
+  int rc = cy_allow_lds(wino2_conv_kernel, lds);
+  if (rc) return rc;
+  wino2_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  CY_LAUNCH_CHECK("cy_conv4x4s2_winograd");
+  return 0;
+}

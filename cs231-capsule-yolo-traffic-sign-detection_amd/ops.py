@@ -79,6 +79,7 @@ def _x_geometry(x, nchw):
 
 
 STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
+USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 
 
@@ -108,6 +109,15 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
     Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
     if not relu and _winograd_ok(k, stride, pad, Cin, nchw):
         return _winograd(x, weight, bias, stats, False, tag)
+    if (USE_WINOGRAD and USE_WINOGRAD_S2 and not relu and k == 4 and stride == 2 and pad == 1 and not nchw
+            and Cin % 8 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and x.is_contiguous()):
+        st = _stream()
+        u = _empty((query('cy_wino2_packed_floats', Cin, Cout),), x)
+        call('cy_wino2_pack_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
+        y = _empty((B, Ho, Wo, Cout), x)
+        with timer.range('conv_wino2_fwd/' + tag):
+            call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), B, Hi, Wi, Cin, Cout, st)
+        return y
     st = _stream()
     wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
     call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, k, k, 0, 0, 1, 0, st)

@@ -90,6 +90,15 @@ long long cy_wino_wgrad_ws_floats(int B, int Cin, int Cout);
 int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws,
                               int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* Fused Winograd F(2x2,2x2) forward for 4x4 / stride 2 / pad 1 convolutions on NHWC (DarkCapsuleNet conv_3..5,
+ * models.py:352-363): the layer is a 2x2 stride-1 convolution of the shifted space-to-depth view of its input, which
+ * needs 9 instead of 16 multiplies per 2x2 outputs.  X [B][H][W][Cin] (H, W even, Cin % 8 == 0) -> Y [B][H/2][W/2][Cout];
+ * U = cy_wino2_pack_weights(W[Cout][Cin][4][4]); bias / stats as in cy_conv_gemm. */
+long long cy_wino2_packed_floats(int Cin, int N);
+int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* stream);
+int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
+                          int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */
 int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream);
 

@@ -133,6 +133,40 @@ def test_conv3x3_winograd_wgrad_matches_direct_and_fp64(case):
     close(dw, dw2, 4e-5, 4e-5 * scale)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 32, 64), (1, 8, 10, 64), (3, 16, 70, 40), (2, 256, 36, 128), (1, 24, 6, 10),
+                                  (2, 8, 128, 64)])
+def test_conv4x4s2_winograd_matches_direct_and_fp64(case):
+    """Fused Winograd F(2x2,2x2) forward of the 4x4 / stride 2 / pad 1 layers (bias, BatchNorm statistics, image
+    borders, partial blocks, padded channels) against torch fp64 and, switched off, the direct implicit GEMM."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    x = rnd((B, Cin, H, H), 81)
+    w = rnd((Cout, Cin, 4, 4), 82, (1.0 / (Cin * 16)) ** 0.5)
+    b = rnd((Cout,), 83, 0.1)
+    zr = F.conv2d(x.double(), w.double(), b.double(), stride=2, padding=1)
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    assert ops.USE_WINOGRAD and ops.USE_WINOGRAD_S2
+    stats = torch.zeros((ops.STATS_COPIES, Cout, 2), dtype=torch.float64, device=dev())
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        z = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 4, 2, 1, False, stats, False, 'c3')
+    finally:
+        ops.timer.enabled = False
+    torch.cuda.synchronize()
+    assert 'conv_wino2_fwd/c3' in ops.timer.summary()
+    stats = stats.sum(0)
+    close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
+    close(stats[:, 0], zr.sum(dim=(0, 2, 3)), 1e-4, 1e-4)
+    close(stats[:, 1], (zr ** 2).sum(dim=(0, 2, 3)), 1e-4, 1e-4)
+    try:
+        ops.USE_WINOGRAD_S2 = False
+        z2 = ops.conv_forward(xg, w.to(dev()), b.to(dev()), 4, 2, 1)
+    finally:
+        ops.USE_WINOGRAD_S2 = True
+    close(z, z2, 4e-5, 4e-5)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
