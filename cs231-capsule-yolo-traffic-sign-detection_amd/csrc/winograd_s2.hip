@@ -34,8 +34,14 @@ struct Wino2Args {
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
 };
 
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+// 18 accumulator tiles = 288 registers, the AGPR file has 256: left to itself the compiler shuttles accumulators
+// between the two files in every chunk (288 v_accvgpr_write per chunk measured).  The MFMAs are therefore written
+// with an explicit register class: positions 0..7 accumulate in AGPRs, position 8 (32 registers) in arch VGPRs.
+__device__ __forceinline__ void mfma_a(f32x16& c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_v(f32x16& c, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
   f32x2 r;
@@ -255,7 +261,8 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
       constexpr int sidx = (SIDX);                                                                  \
       constexpr int xi = sidx >> 3, w_ = sidx & 7, mi = w_ & 1, e = w_ >> 1;                        \
       if (w_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (s2_younger(xi) << 8));                      \
-      acc[xi][mi] = mfma32(fa_[xi & 1][mi][e], fb_[xi & 1][e], acc[xi][mi]);                        \
+      if (xi < 8) mfma_a(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                          \
+      else mfma_v(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                                 \
       if (w_ < 3 && xi + 1 < 9) {                                                                   \
         constexpr int nx = (xi + 1 < 9) ? xi + 1 : 0;                                               \
         if (w_ == 0) fa_[nx & 1][0] = *(const f32x4*)(vb_ + nx * 2 * SLABV);                        \
@@ -307,7 +314,8 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
       const int tl = wm * 64 + mi * 32 + tloc;                // tile within the block: row tl / 16, column tl % 16
       float m[9];
 #pragma unroll
-      for (int xi = 0; xi < 9; ++xi) m[xi] = acc_elem(acc[xi][mi][r]);
+      for (int xi = 0; xi < 8; ++xi) m[xi] = acc_elem(acc[xi][mi][r]);
+      m[8] = acc[8][mi][r];
       const float y00 = (m[0] + m[1]) + (m[3] + m[4]) + bv, y01 = (m[1] + m[2]) + (m[4] + m[5]) + bv;
       const float y10 = (m[3] + m[4]) + (m[6] + m[7]) + bv, y11 = (m[4] + m[5]) + (m[7] + m[8]) + bv;
       float* op = ow + tloc * 128 + li;
