@@ -396,6 +396,325 @@ __global__ void wino2_pack_kernel(const float* __restrict__ W, float* __restrict
   U[idx] = u;
 }
 
+// ================================================================================================ weight gradient
+// dW of the same layers through F(2x2, 2x2): with z the 2x2 tile of dY and d the 3x3 patch of X',
+//   dg'_tile = A^T [(G z G^T) (.) (B^T d B)] A     (same B, G, A as the forward; 9 instead of 16 multiplies),
+// and the sum over tiles and images commutes with A^T . A, so the kernel accumulates 9 GEMMs
+//   dU_xi[q][co] = sum_tiles V_xi[tile][q] Z_xi[tile][co]        (tiles = MFMA k dimension)
+// and wino2_wgrad_finish_kernel adds the per-image partial sums in a fixed order, applies A^T . A and scatters g' back to
+// W[co][c][2a+py][2b+px].  One block = 128 q x 64 co of ONE image, 4 waves (2 x 2), wave = 64 q x 32 co x 9 positions
+// (the forward kernel's MFMA / fragment / slot machinery unchanged); a chunk is 8 tiles (2 x 4): its 5x9 patch of X'
+// (512-byte rows) and 4x8 patch of dY are staged raw in LDS, every thread transforms two tile pairs of one q channel and
+// one tile pair of one output channel as float2 (paired ds_read2st64_b32 of columns c and c + 2, winograd.hip).
+constexpr int WQ = 128, XPW = 45, XPWS = 48, ZPW = 32;   // q channels per block; X' / dY patch pixels (X' rows allocated: 48)
+constexpr int RAWG_BUF = XPWS * WQ + ZPW * 64;           // floats, single buffer
+
+struct Wino2WgradArgs {
+  const float* X; const float* dZ; float* slab;
+  int B, H, W, Cin, Cout, Ho, Wo, gh, gw;
+};
+
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_pair_st64(unsigned addr) {   // (dword[O0*64], dword[O1*64]) as one register pair
+  f32x2 r;
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(r) : "v"(addr), "n"(O0), "n"(O1));
+  return r;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+
+// side work of one chunk (72 slots, fragment fetches in slots 0..2 of every position):
+//   4 T   two paired reads of the raw patches of chunk c+1: dY first (2 pieces), then X' (9 pieces)
+//   5 Z   one row of G z G^T (3 pieces)      6 V  one row of B^T d B of one of the two items (6 pieces)
+//   8     barrier: every wave is past its raw-patch reads
+//   7 S   one float4 of chunk c+2 registers -> raw LDS (8 pieces)      2 G  one global load of chunk c+3 (8 pieces)
+constexpr int G2_T[11] = {3, 4, 5, 6, 7, 11, 12, 13, 14, 15, 19};
+constexpr int G2_Z[3] = {20, 21, 22};
+constexpr int G2_V[6] = {23, 27, 28, 29, 30, 31};
+constexpr int G2_BAR = 35;
+constexpr int G2_S[8] = {36, 37, 38, 39, 43, 44, 45, 46};
+constexpr int G2_G[8] = {47, 51, 52, 53, 54, 55, 59, 60};
+constexpr int g2_kind(int s) {
+  return s2_find(G2_T, 11, s) >= 0 ? 4 : s2_find(G2_Z, 3, s) >= 0 ? 5 : s2_find(G2_V, 6, s) >= 0 ? 6 : s == G2_BAR ? 8
+       : s2_find(G2_S, 8, s) >= 0 ? 7 : s2_find(G2_G, 8, s) >= 0 ? 2 : 0;
+}
+constexpr int g2_idx(int s) {
+  const int k = g2_kind(s);
+  return k == 4 ? s2_find(G2_T, 11, s) : k == 5 ? s2_find(G2_Z, 3, s) : k == 6 ? s2_find(G2_V, 6, s)
+       : k == 7 ? s2_find(G2_S, 8, s) : k == 2 ? s2_find(G2_G, 8, s) : 0;
+}
+constexpr int g2_side_lds(int s) {          // exact: every LDS instruction of the side work is unconditional
+  const int k = g2_kind(s);
+  return k == 4 ? 2 : k == 5 ? 3 : k == 6 ? 3 : k == 7 ? 1 : 0;
+}
+constexpr int g2_younger(int xi) {          // LDS operations younger than position xi's last fragment at its first MFMA
+  if (xi == 0) return 0;
+  int n = g2_side_lds(8 * (xi - 1) + 2);
+  for (int s = 8 * (xi - 1) + 3; s < 8 * xi; ++s) n += s2_frag_lds(s) + g2_side_lds(s);
+  return n > 14 ? 14 : n;
+}
+// LDS operations issued after the side work of slot `from` and before the side work of slot `to`
+constexpr int g2_between(int from, int to) {
+  int n = 0;
+  for (int s = from + 1; s < to; ++s) n += s2_frag_lds(s) + g2_side_lds(s);
+  n += s2_frag_lds(to);
+  return n > 14 ? 14 : n;
+}
+
+__global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Vs = smem;                         // [2][V2_BUF]   A images (X', rows = q)
+  float* Zs = smem + 2 * V2_BUF;            // [2][U2_BUF]   B images (dY, rows = co)
+  float* Rw = smem + 2 * V2_BUF + 2 * U2_BUF;   // raw X' [XPWS][128] then raw dY [32][64]
+
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave & 1, wn = wave >> 1;
+  const int li = lane & 31, lh = lane >> 5;
+  const int nqb = 4 * a.Cin / WQ, ncb = a.Cout / 64;
+  int vid = blockIdx.x;                     // XCD-aware ids: the blocks of one image share an L2
+  if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  const int cob = vid % ncb;
+  const int qb = (vid / ncb) % nqb;
+  const int b = vid / (ncb * nqb);
+  const int nchunk = a.gh * a.gw;
+
+  // ---- loaders: X' item = (pixel = (t >> 5) + 8 q, float4 column t & 31), dY item = (pixel = (t >> 4) + 16 q, t & 15)
+  const int xc4 = t & 31, xprow = t >> 5, zc4 = t & 15, zprow = t >> 4;
+  const int qch = qb * WQ + xc4 * 4;        // this thread's q channel quad: one (py, px) and 4 consecutive c
+  const int qph = qch / a.Cin, qc = qch - qph * a.Cin, qpy = qph >> 1, qpx = qph & 1;
+  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);
+  const char* zimg = (const char*)(a.dZ + (long long)b * a.Ho * a.Wo * a.Cout + cob * 64);
+  int xpr[6], xpc[6];
+  unsigned voffx[6], voffz[2];              // fast path: byte offsets from the chunk's first pixel
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    const int pix = xprow + 8 * q;
+    xpr[q] = pix / 9; xpc[q] = pix - xpr[q] * 9;
+    voffx[q] = pix < XPW ? (unsigned)((((2 * xpr[q] + qpy) * a.W + 2 * xpc[q] + qpx) * a.Cin + qc) * 4) : (unsigned)((((qpy) * a.W + qpx) * a.Cin + qc) * 4);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pix = zprow + 16 * q;
+    voffz[q] = (unsigned)((((pix >> 3) * a.Wo + (pix & 7)) * a.Cout + zc4 * 4) * 4);
+  }
+  f32x4 gx[6], gz[2];
+  unsigned okm = 0;                         // slow path: bit q: gx[q] in range, bit 6+q: gz[q]
+  bool gfast = false;                       // the chunk held in gx/gz was loaded by the fast path
+  auto is_fast = [&](int gy, int gxx) {     // all of the chunk's X' pixels (any py, px) and dY pixels are inside
+    return gy > 0 && gxx > 0 && 8 * gy + 8 <= a.H - 1 && 16 * gxx + 16 <= a.W - 1 && 4 * gy + 4 <= a.Ho && 8 * gxx + 8 <= a.Wo;
+  };
+  auto Gx = [&](int q, int gy, int gxx, bool fast) {
+    if (fast) {
+      gx[q] = *(const f32x4*)(ximg + (size_t)(((8 * gy - 1) * a.W + (16 * gxx - 1)) * a.Cin) * 4 + voffx[q]);
+    } else {
+      const int iy = 2 * (4 * gy + xpr[q]) - 1 + qpy, ix = 2 * (8 * gxx + xpc[q]) - 1 + qpx;
+      const bool ok = (xprow + 8 * q) < XPW && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      gx[q] = *(const f32x4*)(ximg + (ok ? (unsigned)(((iy * a.W + ix) * a.Cin + qc) * 4) : 0u));
+      okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
+    }
+  };
+  auto Gz = [&](int q, int gy, int gxx, bool fast) {
+    if (fast) {
+      gz[q] = *(const f32x4*)(zimg + (size_t)((4 * gy * a.Wo + 8 * gxx) * a.Cout) * 4 + voffz[q]);
+    } else {
+      const int pix = zprow + 16 * q;
+      const int oy = 4 * gy + (pix >> 3), ox = 8 * gxx + (pix & 7);
+      const bool ok = oy < a.Ho && ox < a.Wo;
+      gz[q] = *(const f32x4*)(zimg + (ok ? (unsigned)(((oy * a.Wo + ox) * a.Cout + zc4 * 4) * 4) : 0u));
+      okm = (okm & ~(64u << q)) | ((unsigned)ok << (6 + q));
+    }
+  };
+  auto Sx = [&](int q) {
+    float* dst = Rw + (xprow + 8 * q) * WQ + xc4 * 4;
+    if (gfast) *(f32x4*)dst = gx[q];
+    else *(f32x4*)dst = (okm >> q) & 1 ? gx[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto Sz = [&](int q) {
+    float* dst = Rw + XPWS * WQ + (zprow + 16 * q) * 64 + zc4 * 4;
+    if (gfast) *(f32x4*)dst = gz[q];
+    else *(f32x4*)dst = (okm >> (6 + q)) & 1 ? gz[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+  };
+  auto Gall = [&](int c) {
+    const int gy = c / a.gw, gxx = c - gy * a.gw;
+    const bool fast = is_fast(gy, gxx);
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Gx(q, gy, gxx, fast);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Gz(q, gy, gxx, fast);
+    gfast = fast;
+  };
+  auto Sall = [&]() {
+#pragma unroll
+    for (int q = 0; q < 6; ++q) Sx(q);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) Sz(q);
+  };
+
+  // ---- transform items.  V: q channel vc = t & 127, tile row vr = t >> 7, tile pairs 0 and 1 (two items);
+  //      Z: output channel zc = t & 63, tile row zr = (t >> 6) & 1, tile pair zp = t >> 7.   .x / .y = the pair's two tiles
+  const int vc = t & 127, vr = t >> 7;
+  const int zc = t & 63, zr = (t >> 6) & 1, zp = t >> 7;
+  const float* xraw = Rw + ((2 * vr) * 9) * WQ + vc;                      // X' pixel (2 vr + r, 4 tp + c) -> + ((r*9 + 4tp + c) * 128)
+  const float* zraw = Rw + XPWS * WQ + ((2 * zr) * 8 + 4 * zp) * 64 + zc;  // dY pixel (2 zr + r, 4 zp + c) -> + (r*8 + c) * 64
+  const unsigned xr_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)xraw;
+  const unsigned zr_a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)zraw;
+  const int vdst = vr * SLABV + vc * 4;     // + 2 tp + xi * 2 * SLABV
+  const int zdst = zr * SLABU + zc * 4 + 2 * zp;
+  f32x2 xv[2][3][3], zv[2][2];
+  auto Vrow = [&](float* vb, int it, int R) {   // row R of B^T d B of item (tile pair) it
+    f32x2 t0[3];
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+      t0[cc] = R == 0 ? pk_sub(xv[it][0][cc], xv[it][1][cc]) : R == 1 ? xv[it][1][cc] : pk_sub(xv[it][2][cc], xv[it][1][cc]);
+    float* v = vb + 2 * it;
+    *(f32x2*)(v + (R * 3 + 0) * 2 * SLABV) = pk_sub(t0[0], t0[1]);
+    *(f32x2*)(v + (R * 3 + 1) * 2 * SLABV) = t0[1];
+    *(f32x2*)(v + (R * 3 + 2) * 2 * SLABV) = pk_sub(t0[2], t0[1]);
+  };
+  auto Zrow = [&](float* zb, int R) {       // row R of G z G^T
+    const f32x2 u0 = R == 0 ? zv[0][0] : R == 1 ? pk_add(zv[0][0], zv[1][0]) : zv[1][0];
+    const f32x2 u1 = R == 0 ? zv[0][1] : R == 1 ? pk_add(zv[0][1], zv[1][1]) : zv[1][1];
+    *(f32x2*)(zb + (R * 3 + 0) * 2 * SLABU) = u0;
+    *(f32x2*)(zb + (R * 3 + 1) * 2 * SLABU) = pk_add(u0, u1);
+    *(f32x2*)(zb + (R * 3 + 2) * 2 * SLABU) = u1;
+  };
+  auto Tall_plain = [&]() {                 // prologue only: plain loads (the compiler waits for them itself)
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          xv[it][r][cc] = f32x2{xraw[(r * 9 + 4 * it + cc) * WQ], xraw[(r * 9 + 4 * it + cc + 2) * WQ]};
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc) zv[r][cc] = f32x2{zraw[(r * 8 + cc) * 64], zraw[(r * 8 + cc + 2) * 64]};
+  };
+
+  f32x16 acc[9][2];
+#pragma unroll
+  for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[xi][mi][r] = 0.f;
+
+  // ---- prologue: chunk 0 transformed into buffer 0, chunk 1 raw in LDS, chunk 2 in registers
+  Gall(0);
+  Sall();
+  __syncthreads();
+  Tall_plain();
+#pragma unroll
+  for (int R = 0; R < 3; ++R) { Vrow(Vs + vdst, 0, R); Vrow(Vs + vdst, 1, R); Zrow(Zs + zdst, R); }
+  Gall(nchunk > 1 ? 1 : 0);
+  __syncthreads();
+  Sall();
+  Gall(nchunk > 2 ? 2 : nchunk - 1);
+  __syncthreads();
+
+  const int fragA = lh * SLABV + (wm * 64 + li) * 4;
+  const int fragB = lh * SLABU + (wn * 32 + li) * 4;
+  for (int c = 0; c < nchunk; ++c) {
+    const float* vb_ = Vs + (c & 1) * V2_BUF + fragA;
+    const float* ub_ = Zs + (c & 1) * U2_BUF + fragB;
+    float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // transforms of chunk c+1 (harmless after the last chunk)
+    float* zw_ = Zs + ((c + 1) & 1) * U2_BUF + zdst;
+    const int cg = (c + 3 < nchunk) ? c + 3 : nchunk - 1;
+    const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
+    const bool gf_next = is_fast(ggy, ggx);
+    f32x4 fa_[2][2], fb_[2];
+    fa_[0][0] = *(const f32x4*)(vb_);
+    fa_[0][1] = *(const f32x4*)(vb_ + 128);
+    fb_[0] = *(const f32x4*)(ub_);
+#define G2SLOT(SIDX)                                                                                \
+    {                                                                                               \
+      constexpr int sidx = (SIDX);                                                                  \
+      constexpr int xi = sidx >> 3, w_ = sidx & 7, mi = w_ & 1, e = w_ >> 1;                        \
+      if (w_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (g2_younger(xi) << 8));                      \
+      if (xi < 8) mfma_a(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                          \
+      else mfma_v(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                                 \
+      if (w_ < 3 && xi + 1 < 9) {                                                                   \
+        constexpr int nx = (xi + 1 < 9) ? xi + 1 : 0;                                               \
+        if (w_ == 0) fa_[nx & 1][0] = *(const f32x4*)(vb_ + nx * 2 * SLABV);                        \
+        if (w_ == 1) fa_[nx & 1][1] = *(const f32x4*)(vb_ + nx * 2 * SLABV + 128);                  \
+        if (w_ == 2) fb_[nx & 1] = *(const f32x4*)(ub_ + nx * 2 * SLABU);                           \
+      }                                                                                             \
+      constexpr int kind = g2_kind(sidx), k_ = g2_idx(sidx);                                        \
+      if (kind == 4) {                      /* raw patches of chunk c+1: two pairs */              \
+        if (k_ < 2) {                                                                               \
+          constexpr int r = k_ & 1;                                                                 \
+          zv[r][0] = lds_pair_st64<r * 8 + 0, r * 8 + 2>(zr_a);                                     \
+          zv[r][1] = lds_pair_st64<r * 8 + 1, r * 8 + 3>(zr_a);                                     \
+        } else {                                                                                    \
+          constexpr int i0 = 2 * ((k_ - 2) % 9), i1 = i0 + 1;          /* 18 pairs: (item, row, col) */ \
+          constexpr int p0 = ((i0 % 9) / 3) * 9 + 4 * (i0 / 9) + i0 % 3, p1 = ((i1 % 9) / 3) * 9 + 4 * (i1 / 9) + i1 % 3; \
+          xv[i0 / 9][(i0 % 9) / 3][i0 % 3] = lds_pair_st64<2 * p0, 2 * p0 + 4>(xr_a);               \
+          xv[i1 / 9][(i1 % 9) / 3][i1 % 3] = lds_pair_st64<2 * p1, 2 * p1 + 4>(xr_a);               \
+        }                                                                                           \
+      } else if (kind == 5) {               /* the dY reads (slots 3, 4) are >= 14 LDS operations old */ \
+        if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (g2_between(G2_T[1], G2_Z[0]) << 8));      \
+        Zrow(zw_, k_ % 3);                                                                          \
+      } else if (kind == 6) {               /* all X' reads are older than the Z rows' 9 stores */ \
+        if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (g2_between(G2_T[10], G2_V[0]) << 8));     \
+        Vrow(vw_, (k_ % 6) / 3, (k_ % 6) % 3);                                                      \
+      } else if (kind == 8) {               /* all waves are past their raw-patch reads */         \
+        __builtin_amdgcn_s_barrier();                                                               \
+      } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
+        if (k_ < 6) Sx(k_ % 6); else Sz(k_ & 1);                                                    \
+      } else if (kind == 2) {               /* one global load of chunk c+3 */                     \
+        if (k_ < 6) Gx(k_ % 6, ggy, ggx, gf_next); else Gz(k_ & 1, ggy, ggx, gf_next);              \
+        if (k_ == 7) gfast = gf_next;                                                               \
+      }                                                                                             \
+      __builtin_amdgcn_sched_barrier(0);                                                            \
+    }
+#define G2SLOT8(B) G2SLOT((B)) G2SLOT((B) + 1) G2SLOT((B) + 2) G2SLOT((B) + 3) G2SLOT((B) + 4) G2SLOT((B) + 5) G2SLOT((B) + 6) G2SLOT((B) + 7)
+    G2SLOT8(0) G2SLOT8(8) G2SLOT8(16) G2SLOT8(24) G2SLOT8(32) G2SLOT8(40) G2SLOT8(48) G2SLOT8(56) G2SLOT8(64)
+#undef G2SLOT8
+#undef G2SLOT
+    __syncthreads();
+  }
+
+  // ---- per-image partial dU[xi][q][co] -> slab[b]
+  const int Q = 4 * a.Cin;
+  float* out = a.slab + ((long long)b * 9) * Q * a.Cout;
+  const int co = cob * 64 + wn * 32 + li;
+#pragma unroll
+  for (int xi = 0; xi < 9; ++xi)
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int q = qb * WQ + wm * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = xi < 8 ? acc_elem(acc[xi][mi][r]) : acc[8][mi][r];
+        out[((long long)xi * Q + q) * a.Cout + co] = v;
+      }
+}
+
+// dW[co][c][2a+py][2b+px] = (A^T m A)[a][b], m[xi] = sum_b slab[b][xi][q = (py*2+px)*Cin + c][co], A^T = [[1,1,0],[0,1,1]]
+__global__ void wino2_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dW, int nb, int Cin, int Cout) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int Q = 4 * Cin;
+  if (idx >= (long long)Q * Cout) return;
+  const int co = (int)(idx % Cout), q = (int)(idx / Cout);
+  float m[9];
+#pragma unroll
+  for (int xi = 0; xi < 9; ++xi) m[xi] = 0.f;
+  for (int bb = 0; bb < nb; ++bb)
+#pragma unroll
+    for (int xi = 0; xi < 9; ++xi) m[xi] += slab[(((long long)bb * 9 + xi) * Q + q) * Cout + co];
+  const int ph = q / Cin, c = q - ph * Cin, py = ph >> 1, px = ph & 1;
+  float* o = dW + ((long long)co * Cin + c) * 16;
+  o[(0 + py) * 4 + 0 + px] = (m[0] + m[1]) + (m[3] + m[4]);
+  o[(0 + py) * 4 + 2 + px] = (m[1] + m[2]) + (m[4] + m[5]);
+  o[(2 + py) * 4 + 0 + px] = (m[3] + m[4]) + (m[6] + m[7]);
+  o[(2 + py) * 4 + 2 + px] = (m[4] + m[5]) + (m[7] + m[8]);
+}
+
 }  // namespace
 
 extern "C" long long cy_wino2_packed_floats(int Cin, int N) {
@@ -431,5 +750,32 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   if (rc) return rc;
   wino2_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd");
+  return 0;
+}
+
+extern "C" long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout) { return (long long)B * 9 * 4 * Cin * Cout; }
+
+extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int W, int Cin,
+                                           int Cout, void* stream) {
+  CY_REQUIRE(X && dZ && dW && ws && B > 0 && H > 0 && W > 0, "cy_conv4x4s2_winograd_wgrad: bad arguments");
+  CY_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "cy_conv4x4s2_winograd_wgrad: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
+  CY_REQUIRE(H % 2 == 0 && W % 2 == 0, "cy_conv4x4s2_winograd_wgrad: H=%d, W=%d must be even", H, W);
+  CY_REQUIRE((((uintptr_t)X | (uintptr_t)dZ) & 15) == 0, "cy_conv4x4s2_winograd_wgrad: operands must be 16-byte aligned");
+  CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd_wgrad: image too large for 32-bit offsets");
+  Wino2WgradArgs a;
+  a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.Ho = H / 2; a.Wo = W / 2;
+  a.gh = (a.Ho + 3) / 4; a.gw = (a.Wo + 7) / 8;
+  const long long blocks = (long long)B * (4 * Cin / WQ) * (Cout / 64);
+  CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_wgrad: grid too large");
+  const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + RAWG_BUF) * 4;
+  int rc = cy_allow_lds(wino2_wgrad_kernel, lds);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  wino2_wgrad_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
+  CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad");
+  const long long n = (long long)4 * Cin * Cout;
+  wino2_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B, Cin, Cout);
+  CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad(finish)");
   return 0;
 }

@@ -192,6 +192,12 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
         with timer.range('conv_wino_wgrad/' + tag):
             call('cy_conv3x3_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cin, Cout, st)
         return dW
+    if (USE_WINOGRAD and USE_WINOGRAD_S2 and k == 4 and stride == 2 and pad == 1 and not nchw and Cin % 32 == 0
+            and Cout % 64 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and x.is_contiguous() and dz.is_contiguous()):
+        ws = _empty((query('cy_wino2_wgrad_ws_floats', B, Cin, Cout),), dz)
+        with timer.range('conv_wino2_wgrad/' + tag):
+            call('cy_conv4x4s2_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cin, Cout, st)
+        return dW
     a = ConvWgrad(X=x.data_ptr(), dZ=dz.data_ptr(), dW=dW.data_ptr(), slabs=None,
                   xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                   KH=k, KW=k, stride=stride, pad=pad)

@@ -98,6 +98,12 @@ long long cy_wino2_packed_floats(int Cin, int N);
 int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* stream);
 int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
                           int B, int H, int W, int Cin, int Cout, void* stream);
+/* Weight gradient of the same layers through F(2x2,2x2): dW[Cout][Cin][4][4] from X[B][H][W][Cin] and
+ * dZ[B][H/2][W/2][Cout].  Cin % 32 == 0, Cout % 64 == 0, H and W even.  ws: cy_wino2_wgrad_ws_floats(B, Cin, Cout) floats
+ * (per-image partial sums in the Winograd domain, reduced in a fixed order: deterministic). */
+long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout);
+int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws,
+                                int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */
 int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream);

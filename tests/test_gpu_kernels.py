@@ -167,6 +167,39 @@ def test_conv4x4s2_winograd_matches_direct_and_fp64(case):
     close(z, z2, 4e-5, 4e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 32, 64), (1, 32, 10, 64), (3, 32, 70, 128), (2, 256, 36, 64), (5, 64, 6, 64),
+                                  (2, 128, 48, 256)])
+def test_conv4x4s2_winograd_wgrad_matches_direct_and_fp64(case):
+    """Winograd F(2x2,2x2) weight gradient of the 4x4 / stride 2 / pad 1 layers (image borders, partially filled tile
+    groups, q blocks that span two (py, px) classes) against torch fp64 and the direct MFMA weight-gradient kernel."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    x = rnd((B, Cin, H, H), 91)
+    w = rnd((Cout, Cin, 4, 4), 92, (1.0 / (Cin * 16)) ** 0.5)
+    wd = w.double().requires_grad_(True)
+    zr = F.conv2d(x.double(), wd, None, stride=2, padding=1)
+    gz = rnd(tuple(zr.shape), 94)
+    zr.backward(gz.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        dw = ops.conv_wgrad(xg, gzd, 4, 2, 1, False, 'wg')
+    finally:
+        ops.timer.enabled = False
+    torch.cuda.synchronize()
+    assert 'conv_wino2_wgrad/wg' in ops.timer.summary()
+    scale = wd.grad.abs().max().item()
+    close(dw, wd.grad, 2e-5, 2e-5 * scale)
+    try:
+        ops.USE_WINOGRAD_S2 = False
+        dw2 = ops.conv_wgrad(xg, gzd, 4, 2, 1)
+    finally:
+        ops.USE_WINOGRAD_S2 = True
+    close(dw, dw2, 4e-5, 4e-5 * scale)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
