@@ -412,6 +412,7 @@ constexpr int RAWG_BUF = XPWS * WQ + ZPW * 64;           // floats, single buffe
 struct Wino2WgradArgs {
   const float* X; const float* dZ; float* slab;
   int B, H, W, Cin, Cout, Ho, Wo, gh, gw;
+  int nsplit;                               // tile groups of one image are cut into nsplit ranges (more blocks for small layers)
 };
 
 template <int O0, int O1>
@@ -479,8 +480,11 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
   if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int cob = vid % ncb;
   const int qb = (vid / ncb) % nqb;
-  const int b = vid / (ncb * nqb);
-  const int nchunk = a.gh * a.gw;
+  const int bs = vid / (ncb * nqb);         // image * nsplit + split
+  const int b = bs / a.nsplit, sp = bs - b * a.nsplit;
+  const int ngroups = a.gh * a.gw;
+  const int cbeg = (int)((long long)ngroups * sp / a.nsplit), cend = (int)((long long)ngroups * (sp + 1) / a.nsplit);
+  const int nchunk = cend - cbeg;           // >= 1 (nsplit <= ngroups)
 
   // ---- loaders: X' item = (pixel = (t >> 5) + 8 q, float4 column t & 31), dY item = (pixel = (t >> 4) + 16 q, t & 15)
   const int xc4 = t & 31, xprow = t >> 5, zc4 = t & 15, zprow = t >> 4;
@@ -539,7 +543,7 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
     else *(f32x4*)dst = (okm >> (6 + q)) & 1 ? gz[q] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto Gall = [&](int c) {
-    const int gy = c / a.gw, gxx = c - gy * a.gw;
+    const int gy = (cbeg + c) / a.gw, gxx = (cbeg + c) - gy * a.gw;
     const bool fast = is_fast(gy, gxx);
 #pragma unroll
     for (int q = 0; q < 6; ++q) Gx(q, gy, gxx, fast);
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
     const float* ub_ = Zs + (c & 1) * U2_BUF + fragB;
     float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // transforms of chunk c+1 (harmless after the last chunk)
     float* zw_ = Zs + ((c + 1) & 1) * U2_BUF + zdst;
-    const int cg = (c + 3 < nchunk) ? c + 3 : nchunk - 1;
+    const int cg = cbeg + ((c + 3 < nchunk) ? c + 3 : nchunk - 1);
     const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
     const bool gf_next = is_fast(ggy, ggx);
     f32x4 fa_[2][2], fb_[2];
@@ -681,7 +685,7 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
 
   // ---- per-image partial dU[xi][q][co] -> slab[b]
   const int Q = 4 * a.Cin;
-  float* out = a.slab + ((long long)b * 9) * Q * a.Cout;
+  float* out = a.slab + ((long long)bs * 9) * Q * a.Cout;
   const int co = cob * 64 + wn * 32 + li;
 #pragma unroll
   for (int xi = 0; xi < 9; ++xi)
@@ -753,7 +757,16 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   return 0;
 }
 
-extern "C" long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout) { return (long long)B * 9 * 4 * Cin * Cout; }
+// tile-group ranges per image: enough blocks to cover the chip (one block per CU) when B * 4Cin/128 * Cout/64 is small
+static int wino2_wgrad_splits(int B, int Cin, int Cout) {
+  const long long base = (long long)B * (4 * Cin / WQ) * (Cout / 64);
+  int s = 1;
+  while (base * s < 192 && s < 8) s *= 2;
+  return s;
+}
+extern "C" long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout) {
+  return (long long)B * wino2_wgrad_splits(B, Cin, Cout) * 9 * 4 * Cin * Cout;
+}
 
 extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int W, int Cin,
                                            int Cout, void* stream) {
@@ -766,7 +779,9 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.Ho = H / 2; a.Wo = W / 2;
   a.gh = (a.Ho + 3) / 4; a.gw = (a.Wo + 7) / 8;
-  const long long blocks = (long long)B * (4 * Cin / WQ) * (Cout / 64);
+  a.nsplit = wino2_wgrad_splits(B, Cin, Cout);
+  if (a.nsplit > a.gh * a.gw) a.nsplit = 1;             // (the workspace is sized for the larger count)
+  const long long blocks = (long long)B * a.nsplit * (4 * Cin / WQ) * (Cout / 64);
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_wgrad: grid too large");
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + RAWG_BUF) * 4;
   int rc = cy_allow_lds(wino2_wgrad_kernel, lds);
@@ -775,7 +790,7 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   wino2_wgrad_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad");
   const long long n = (long long)4 * Cin * Cout;
-  wino2_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B, Cin, Cout);
+  wino2_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B * a.nsplit, Cin, Cout);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad(finish)");
   return 0;
 }
