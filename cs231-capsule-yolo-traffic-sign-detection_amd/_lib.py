@@ -56,8 +56,8 @@ _SIGS = {
     'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_wino2_pack_weights': [_P, _P, _I, _I, _P],
-    'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
-    'cy_conv4x4s2_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    'cy_conv4x4s2_winograd_wgrad': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_bn_finalize': [_P, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     'cy_bn_eval_scale_shift': [_P, _P, _P, _P, _F, _P, _P, _I, _P],
     'cy_affine_act': [_P, _P, _P, _P, _F, _L, _I, _P],

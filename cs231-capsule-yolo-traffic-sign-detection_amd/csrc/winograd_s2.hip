@@ -31,6 +31,7 @@ constexpr int NRAWQ = 5, NUQ = 5;           // float4 items per thread: 1122 pat
 
 struct Wino2Args {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
+  const float* in_scale; const float* in_shift; float in_slope;   // optional: the input is lrelu(X * scale[c] + shift[c])
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
 };
 
@@ -47,6 +48,18 @@ __device__ __forceinline__ f32x2 pk_sub(f32x2 x, f32x2 y) {
   f32x2 r;
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
   return r;
+}
+// lrelu(v * sc + sh) on 4 channels with packed math (the producer's BatchNorm + LeakyReLU applied on the way into LDS,
+// so that the activation tensor never exists in HBM); slope in (0, 1]: lrelu(y) = max(y, slope * y)
+__device__ __forceinline__ f32x4 affine_lrelu4(f32x4 v, f32x4 sc, f32x4 sh, float slope) {
+  f32x2 lo = {v[0], v[1]}, hi = {v[2], v[3]};
+  const f32x2 sl = {slope, slope};
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(lo), "v"(f32x2{sc[0], sc[1]}), "v"(f32x2{sh[0], sh[1]}));
+  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(hi), "v"(f32x2{sc[2], sc[3]}), "v"(f32x2{sh[2], sh[3]}));
+  f32x2 lo2, hi2;
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo2) : "v"(lo), "v"(sl));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi2) : "v"(hi), "v"(sl));
+  return f32x4{fmaxf(lo[0], lo2[0]), fmaxf(lo[1], lo2[1]), fmaxf(hi[0], hi2[0]), fmaxf(hi[1], hi2[1])};
 }
 __device__ __forceinline__ float acc_elem(float a_elem) {   // one accumulator element, read where the statement stands
   float x;
@@ -98,11 +111,17 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   float* Vs = smem;                         // [2][V2_BUF]
   float* Us = smem + 2 * V2_BUF;            // [2][U2_BUF]
   float* Rs = smem + 2 * V2_BUF + 2 * U2_BUF;   // [2][RAW2_BUF]
+  float* Aff = Rs + 2 * RAW2_BUF;           // [2][Cin] input scale / shift (only with in_scale)
 
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 31, lh = lane >> 5;
+  const bool affine = a.in_scale != nullptr;      // uniform
+  if (affine) {
+    for (int i = t; i < a.Cin; i += 256) { Aff[i] = a.in_scale[i]; Aff[a.Cin + i] = a.in_shift[i]; }
+    __syncthreads();
+  }
 
   unsigned vid = blockIdx.x;                // XCD-aware ids: the Np/64 blocks of one patch share an L2 (winograd.hip)
   if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -165,10 +184,17 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
       okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
     }
   };
+  f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};     // scale / shift of the chunk that is being stored
+  auto set_affine = [&](int f) {            // f = chunk whose patch goes to LDS next
+    if (!affine) return;
+    const int c0 = (f % cpp) * 8 + kq_of_thread * 4;
+    asc = *(const f32x4*)(Aff + c0); ash = *(const f32x4*)(Aff + a.Cin + c0);
+  };
   auto Sraw1 = [&](float* rb, int q, const f32x4& src) {
     if (roff[q] < 0) return;
-    if (blk_fast) *(f32x4*)(rb + roff[q]) = src;
-    else *(f32x4*)(rb + roff[q]) = (okm >> q) & 1 ? src : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 v = affine ? affine_lrelu4(src, asc, ash, a.in_slope) : src;
+    if (blk_fast) *(f32x4*)(rb + roff[q]) = v;
+    else *(f32x4*)(rb + roff[q]) = (okm >> q) & 1 ? v : f32x4{0.f, 0.f, 0.f, 0.f};    // padding stays exactly 0
   };
   auto GU1 = [&](int q, int f, f32x4& dst) {
     dst = *(const f32x4*)((const char*)a.U + (long long)f * uchunk * 4 + uvoff[q]);
@@ -220,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw[q]);
 #pragma unroll
     for (int q = 0; q < NUQ; ++q) GU1(q, 0, gu[q]);
+    set_affine(0);
 #pragma unroll
     for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs, q, graw[q]);
     const int f1 = nchunk > 1 ? 1 : 0, f2 = nchunk > 2 ? 2 : nchunk - 1;
@@ -232,6 +259,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     for (int q = 0; q < NUQ; ++q) GU1(q, f1, gu[q]);
     __syncthreads();
     Tall(0, 0);
+    set_affine(f1);
 #pragma unroll
     for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs + RAW2_BUF, q, graw1[q]);
     chunk_pos(f2, py, px, c0);
@@ -252,6 +280,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     const int fr = (c + 3 < nchunk) ? c + 3 : nchunk - 1;           // G_raw(c+3)
     int rpy, rpx, rc0;
     chunk_pos(fr, rpy, rpx, rc0);
+    set_affine((c + 2 < nchunk) ? c + 2 : nchunk - 1);              // the chunk S_raw stores during this one
     f32x4 fa_[2][2], fb_[2];                // fragment sets, indexed by position & 1
     fa_[0][0] = *(const f32x4*)(vb_);
     fa_[0][1] = *(const f32x4*)(vb_ + 128);
@@ -411,6 +440,7 @@ constexpr int RAWG_BUF = XPWS * WQ + ZPW * 64;           // floats, single buffe
 
 struct Wino2WgradArgs {
   const float* X; const float* dZ; float* slab;
+  const float* in_scale; const float* in_shift; float in_slope;   // optional: the layer input is lrelu(X * scale[c] + shift[c])
   int B, H, W, Cin, Cout, Ho, Wo, gh, gw;
   int nsplit;                               // tile groups of one image are cut into nsplit ranges (more blocks for small layers)
 };
@@ -532,10 +562,14 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
       okm = (okm & ~(64u << q)) | ((unsigned)ok << (6 + q));
     }
   };
+  const bool affine = a.in_scale != nullptr;      // uniform; this thread's 4 input channels never change
+  const f32x4 asc = affine ? *(const f32x4*)(a.in_scale + qc) : f32x4{1.f, 1.f, 1.f, 1.f};
+  const f32x4 ash = affine ? *(const f32x4*)(a.in_shift + qc) : f32x4{0.f, 0.f, 0.f, 0.f};
   auto Sx = [&](int q) {
     float* dst = Rw + (xprow + 8 * q) * WQ + xc4 * 4;
-    if (gfast) *(f32x4*)dst = gx[q];
-    else *(f32x4*)dst = (okm >> q) & 1 ? gx[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 v = affine ? affine_lrelu4(gx[q], asc, ash, a.in_slope) : gx[q];
+    if (gfast) *(f32x4*)dst = v;
+    else *(f32x4*)dst = (okm >> q) & 1 ? v : f32x4{0.f, 0.f, 0.f, 0.f};    // padding stays exactly 0
   };
   auto Sz = [&](int q) {
     float* dst = Rw + XPWS * WQ + (zprow + 16 * q) * 64 + zc4 * 4;
@@ -734,8 +768,11 @@ extern "C" int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin
   return 0;
 }
 
-extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, int B, int H,
+extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
+                                     const float* in_scale, const float* in_shift, float in_slope, int B, int H,
                                      int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "cy_conv4x4s2_winograd: in_scale and in_shift go together");
+  CY_REQUIRE(in_scale == nullptr || (in_slope > 0.f && in_slope <= 1.f), "cy_conv4x4s2_winograd: in_slope must be in (0, 1]");
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv4x4s2_winograd: bad arguments");
   CY_REQUIRE(Cin % 8 == 0 && Cin >= 8, "cy_conv4x4s2_winograd: Cin=%d must be a multiple of 8", Cin);
   CY_REQUIRE(H % 2 == 0 && W % 2 == 0, "cy_conv4x4s2_winograd: H=%d, W=%d must be even", H, W);
@@ -743,13 +780,15 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd: image too large for 32-bit offsets");
   Wino2Args a;
   a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.Np = (Cout + 63) / 64 * 64;
   a.Ho = H / 2; a.Wo = W / 2;
   a.tbh = (a.Ho + 2 * TR2 - 1) / (2 * TR2); a.tbw = (a.Wo + 2 * TC2 - 1) / (2 * TC2);
   const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / 64);
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd: grid too large");
-  const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF) * 4;
+  const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF + (in_scale ? 2 * Cin : 0)) * 4;
+  CY_REQUIRE(lds <= 160 * 1024, "cy_conv4x4s2_winograd: Cin=%d too large for the fused input affine", Cin);
   int rc = cy_allow_lds(wino2_conv_kernel, lds);
   if (rc) return rc;
   wino2_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
@@ -768,8 +807,11 @@ extern "C" long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout) {
   return (long long)B * wino2_wgrad_splits(B, Cin, Cout) * 9 * 4 * Cin * Cout;
 }
 
-extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int W, int Cin,
+extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, const float* in_scale,
+                                           const float* in_shift, float in_slope, int B, int H, int W, int Cin,
                                            int Cout, void* stream) {
+  CY_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "cy_conv4x4s2_winograd_wgrad: in_scale and in_shift go together");
+  CY_REQUIRE(in_scale == nullptr || (in_slope > 0.f && in_slope <= 1.f), "cy_conv4x4s2_winograd_wgrad: in_slope must be in (0, 1]");
   CY_REQUIRE(X && dZ && dW && ws && B > 0 && H > 0 && W > 0, "cy_conv4x4s2_winograd_wgrad: bad arguments");
   CY_REQUIRE(Cin % 32 == 0 && Cout % 64 == 0, "cy_conv4x4s2_winograd_wgrad: Cin=%d must be a multiple of 32, Cout=%d of 64", Cin, Cout);
   CY_REQUIRE(H % 2 == 0 && W % 2 == 0, "cy_conv4x4s2_winograd_wgrad: H=%d, W=%d must be even", H, W);
@@ -777,6 +819,7 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd_wgrad: image too large for 32-bit offsets");
   Wino2WgradArgs a;
   a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
   a.Ho = H / 2; a.Wo = W / 2;
   a.gh = (a.Ho + 3) / 4; a.gw = (a.Wo + 7) / 8;
   a.nsplit = wino2_wgrad_splits(B, Cin, Cout);

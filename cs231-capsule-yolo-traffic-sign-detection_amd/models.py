@@ -58,21 +58,45 @@ class FusedBackbone(nn.Sequential):
     """nn.Sequential of conv_k / bn_k / relu_k / maxpool_k / drop_k children (reference names);
     forward walks the children and fuses each conv -> bn -> relu triple into one conv block."""
 
+    def _triple(self, mods, i):
+        """(bn, act, index after the block) of the conv at position i."""
+        bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], HipBatchNorm2d) else None
+        j = i + (2 if bn is not None else 1)
+        act = mods[j] if j < len(mods) and isinstance(mods[j], HipLeakyReLU) else None
+        return bn, act, j + (1 if act is not None else 0)
+
     def forward(self, x, nchw_in=True):
         names, mods = zip(*self.named_children())
         i = 0
+        lazy = None                               # (scale, shift, slope) of a producer that deferred its activation
         while i < len(mods):
             m = mods[i]
             if isinstance(m, HipConv2d):
-                bn = mods[i + 1] if i + 1 < len(mods) and isinstance(mods[i + 1], HipBatchNorm2d) else None
-                j = i + (2 if bn is not None else 1)
-                act = mods[j] if j < len(mods) and isinstance(mods[j], HipLeakyReLU) else None
-                cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, act.slope if act is not None else None,
-                                       names[i])
-                x = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
-                                   bn.bias if bn is not None else None, cfg)
+                bn, act, nxt = self._triple(mods, i)
+                slope = act.slope if act is not None else None
+                # hand the raw output + scale/shift to the next block when that block is a 4x4 / stride-2 layer whose
+                # Winograd forward and weight-gradient kernels apply BatchNorm + LeakyReLU on their loads: the
+                # activation tensor (5.7 GB after conv_2 at the headline shape) is never written
+                defer = False
+                if (ops.FUSE_INPUT_AFFINE and bn is not None and slope is not None and 0.0 < slope <= 1.0
+                        and nxt < len(mods) and isinstance(mods[nxt], HipConv2d)):
+                    n = mods[nxt]
+                    hin = x.shape[2] if nchw_in else x.shape[1]
+                    win = x.shape[3] if nchw_in else x.shape[2]
+                    ho = (hin + 2 * m.padding - m.k) // m.stride + 1
+                    wo = (win + 2 * m.padding - m.k) // m.stride + 1
+                    defer = ops.s2_fusable(n.k, n.stride, n.padding, m.weight.shape[0], n.weight.shape[0], ho, wo)
+                cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, slope, names[i], defer_act=defer,
+                                       in_slope=lazy[2] if lazy is not None else None)
+                out = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
+                                     bn.bias if bn is not None else None, cfg,
+                                     lazy[0] if lazy is not None else None, lazy[1] if lazy is not None else None)
+                if defer:
+                    x, lazy = out[0], (out[1], out[2], slope)
+                else:
+                    x, lazy = out, None
                 nchw_in = False
-                i = j + (1 if act is not None else 0)
+                i = nxt
             elif isinstance(m, nn.Dropout):
                 if m.p > 0 and self.training:
                     x = F.dropout(x, m.p, True)      # torch RNG kept (SURVEY section 2.1: RNG parity)

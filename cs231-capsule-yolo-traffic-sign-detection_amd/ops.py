@@ -83,6 +83,16 @@ USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 
 
+FUSE_INPUT_AFFINE = True  # a BN+LeakyReLU block in front of a 4x4/stride-2 block hands over its raw output + scale/shift
+
+
+def s2_fusable(k, stride, pad, cin, cout, hi, wi, nchw=False):
+    """The 4x4 / stride-2 Winograd forward AND weight-gradient kernels both take this layer (then they can apply the
+    producer's BatchNorm + LeakyReLU on their input loads)."""
+    return (USE_WINOGRAD and USE_WINOGRAD_S2 and k == 4 and stride == 2 and pad == 1 and not nchw and cin % 32 == 0
+            and cout % 64 == 0 and hi % 2 == 0 and wi % 2 == 0)
+
+
 def _winograd_ok(k, stride, pad, cin, nchw):
     return USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and not nchw and cin % 8 == 0 and cin >= 8
 
@@ -101,12 +111,15 @@ def _winograd(x, weight, bias, stats, transpose, tag):
     return y
 
 
-def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv'):
+def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv', in_affine=None):
     """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
     x, weight = _f32(x, 'conv input'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     Cout = weight.shape[0]
     Ho, Wo = (Hi + 2 * pad - k) // stride + 1, (Wi + 2 * pad - k) // stride + 1
+    if in_affine is not None and not s2_fusable(k, stride, pad, Cin, Cout, Hi, Wi, nchw):
+        raise _lib.HipExtensionError('a fused input affine needs the 4x4/stride-2 Winograd kernels (got k=%d s=%d Cin=%d Cout=%d)'
+                                     % (k, stride, Cin, Cout))
     if not relu and _winograd_ok(k, stride, pad, Cin, nchw):
         return _winograd(x, weight, bias, stats, False, tag)
     if (USE_WINOGRAD and USE_WINOGRAD_S2 and not relu and k == 4 and stride == 2 and pad == 1 and not nchw
@@ -115,8 +128,10 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
         u = _empty((query('cy_wino2_packed_floats', Cin, Cout),), x)
         call('cy_wino2_pack_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
         y = _empty((B, Ho, Wo, Cout), x)
+        isc, ish, isl = in_affine if in_affine is not None else (None, None, 1.0)
         with timer.range('conv_wino2_fwd/' + tag):
-            call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), B, Hi, Wi, Cin, Cout, st)
+            call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
+                 float(isl), B, Hi, Wi, Cin, Cout, st)
         return y
     st = _stream()
     wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
@@ -181,7 +196,7 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
     return dx
 
 
-def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
+def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv', in_affine=None):
     x, dz = _f32(x, 'conv input'), _f32(dz, 'grad')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     _, Ho, Wo, Cout = dz.shape
@@ -195,9 +210,13 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
     if (USE_WINOGRAD and USE_WINOGRAD_S2 and k == 4 and stride == 2 and pad == 1 and not nchw and Cin % 32 == 0
             and Cout % 64 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and x.is_contiguous() and dz.is_contiguous()):
         ws = _empty((query('cy_wino2_wgrad_ws_floats', B, Cin, Cout),), dz)
+        isc, ish, isl = in_affine if in_affine is not None else (None, None, 1.0)
         with timer.range('conv_wino2_wgrad/' + tag):
-            call('cy_conv4x4s2_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cin, Cout, st)
+            call('cy_conv4x4s2_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), _ptr(isc), _ptr(ish), float(isl),
+                 B, Hi, Wi, Cin, Cout, st)
         return dW
+    if in_affine is not None:
+        raise _lib.HipExtensionError('a fused input affine needs the 4x4/stride-2 Winograd weight-gradient kernel')
     a = ConvWgrad(X=x.data_ptr(), dZ=dz.data_ptr(), dW=dW.data_ptr(), slabs=None,
                   xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                   KH=k, KW=k, stride=stride, pad=pad)
@@ -211,8 +230,10 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv'):
 class ConvBlockCfg(object):
     """Static description of one conv (+BatchNorm) (+activation) block."""
 
-    def __init__(self, k, stride, pad, nchw_in=False, bn=None, slope=None, name='conv'):
+    def __init__(self, k, stride, pad, nchw_in=False, bn=None, slope=None, name='conv', defer_act=False, in_slope=None):
         self.k, self.stride, self.pad, self.nchw_in, self.name = k, stride, pad, nchw_in, name
+        self.defer_act = defer_act   # return (z, scale, shift): the consumer applies BatchNorm + LeakyReLU on its loads
+        self.in_slope = in_slope     # not None: x is the producer's raw output, in_scale / in_shift come with it
         self.bn = bn            # module with running_mean / running_var / momentum / eps / training, or None
         self.slope = slope      # None: no activation; 0.0: ReLU; else LeakyReLU slope
 
@@ -221,16 +242,20 @@ class _ConvBlock(torch.autograd.Function):
     """conv -> [BatchNorm (batch statistics from the conv epilogue)] -> [Leaky]ReLU, saving only x and z."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, cfg):
+    def forward(ctx, x, weight, bias, gamma, beta, cfg, in_scale=None, in_shift=None):
         x = _f32(x, 'conv input')
         weight = _f32(weight, 'conv weight')
         st = _stream()
         N = weight.shape[0]
         bn = cfg.bn
         ctx.cfg, ctx.has_bias, ctx.bn_train = cfg, bias is not None, False
+        ina = (in_scale, in_shift, float(cfg.in_slope)) if cfg.in_slope is not None else None
+        ctx.in_affine = ina
         if bn is None:
+            if cfg.defer_act:
+                raise _lib.HipExtensionError('defer_act needs a BatchNorm block')
             relu = cfg.slope is not None and cfg.slope == 0.0
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, relu, cfg.name)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, relu, cfg.name, ina)
             out = z
             if cfg.slope is not None and not relu:
                 out = torch.empty_like(z)
@@ -241,7 +266,7 @@ class _ConvBlock(torch.autograd.Function):
         mean, invstd = _empty((N,), x), _empty((N,), x)
         if bn.training:
             stats = torch.zeros((STATS_COPIES, N, 2), dtype=torch.float64, device=x.device)
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name, ina)
             P = z.numel() // N
             call('cy_bn_finalize', _ptr(stats), P, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
                  _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean),
@@ -249,18 +274,21 @@ class _ConvBlock(torch.autograd.Function):
             bn.num_batches_tracked += 1
             ctx.bn_train = True
         else:
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False, cfg.name)
+            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False, cfg.name, ina)
             P = z.numel() // N
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                  float(bn.eps), _ptr(scale), _ptr(shift), N, st)
-        out = torch.empty_like(z)
         slope = 1.0 if cfg.slope is None else float(cfg.slope)
-        call('cy_affine_act', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), slope, P, N, st)
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma)
+        if cfg.defer_act:                     # the consumer block applies lrelu(z * scale + shift) on its loads
+            ctx.mark_non_differentiable(scale, shift)
+            return z, scale, shift
+        out = torch.empty_like(z)
+        call('cy_affine_act', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), slope, P, N, st)
         return out
 
     @staticmethod
-    def backward(ctx, da):
+    def backward(ctx, da, *unused):
         cfg = ctx.cfg
         da = _f32(da, 'grad')
         st = _stream()
@@ -293,17 +321,20 @@ class _ConvBlock(torch.autograd.Function):
             if ctx.has_bias:
                 # a bias in front of BatchNorm has an analytically zero gradient: sum(dz) == 0
                 dbias = torch.zeros((N,), dtype=torch.float32, device=z.device)
-        dW = conv_wgrad(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, cfg.name)
+        dW = conv_wgrad(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, cfg.name, ctx.in_affine)
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.nchw_in:
                 raise _lib.HipExtensionError('input gradient of an NCHW-input convolution is not implemented')
             dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, cfg.name)
-        return dx, dW, dbias, dgamma, dbeta, None
+        return dx, dW, dbias, dgamma, dbeta, None, None, None
 
 
-def conv_block(x, weight, bias, gamma, beta, cfg):
-    return _ConvBlock.apply(x, weight, bias, gamma, beta, cfg)
+def conv_block(x, weight, bias, gamma, beta, cfg, in_scale=None, in_shift=None):
+    """One conv (+BN) (+activation) block.  cfg.defer_act: returns (z, scale, shift) instead of the activation; the next
+    block then runs with cfg.in_slope set and these tensors as in_scale / in_shift (its input gradient is the gradient
+    with respect to the ACTIVATED value, which is what this block's backward expects)."""
+    return _ConvBlock.apply(x, weight, bias, gamma, beta, cfg, in_scale, in_shift)
 
 
 # ------------------------------------------------------------------------------------------------ routing

@@ -96,13 +96,18 @@ int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float* dW, float*
  * U = cy_wino2_pack_weights(W[Cout][Cin][4][4]); bias / stats as in cy_conv_gemm. */
 long long cy_wino2_packed_floats(int Cin, int N);
 int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* stream);
+/* in_scale / in_shift [Cin] (both or neither) + in_slope in (0, 1]: the layer's input is lrelu(X * in_scale[c] + in_shift[c])
+ * -- the producer's BatchNorm + LeakyReLU (models.py:349-351) applied on the way into LDS, so that the activation tensor
+ * of the previous layer is never written to HBM (X is then the previous layer's raw convolution output). */
 int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
+                          const float* in_scale, const float* in_shift, float in_slope,
                           int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through F(2x2,2x2): dW[Cout][Cin][4][4] from X[B][H][W][Cin] and
  * dZ[B][H/2][W/2][Cout].  Cin % 32 == 0, Cout % 64 == 0, H and W even.  ws: cy_wino2_wgrad_ws_floats(B, Cin, Cout) floats
  * (per-image partial sums in the Winograd domain, reduced in a fixed order: deterministic). */
 long long cy_wino2_wgrad_ws_floats(int B, int Cin, int Cout);
 int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws,
+                                const float* in_scale, const float* in_shift, float in_slope,
                                 int B, int H, int W, int Cin, int Cout, void* stream);
 
 /* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */

@@ -200,6 +200,30 @@ def test_conv4x4s2_winograd_wgrad_matches_direct_and_fp64(case):
     close(dw, dw2, 4e-5, 4e-5 * scale)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 32, 64), (3, 32, 70, 128), (1, 256, 12, 64)])
+def test_conv4x4s2_winograd_fused_input_affine(case):
+    """The 4x4 / stride-2 Winograd forward and weight gradient with the producer's BatchNorm + LeakyReLU applied on
+    their loads (X = raw conv output of the previous layer) against torch fp64 on the explicitly activated input;
+    the zero padding must stay zero (not lrelu(shift))."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    zprev = rnd((B, Cin, H, H), 101)
+    sc, sh = rnd((Cin,), 102, 0.5) + 1.0, rnd((Cin,), 103, 0.5)
+    w = rnd((Cout, Cin, 4, 4), 104, (1.0 / (Cin * 16)) ** 0.5)
+    a = F.leaky_relu(zprev.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1), 0.1)
+    wd = w.double().requires_grad_(True)
+    zr = F.conv2d(a, wd, None, stride=2, padding=1)
+    gz = rnd(tuple(zr.shape), 105)
+    zr.backward(gz.double())
+    zg = zprev.permute(0, 2, 3, 1).contiguous().to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    ina = (sc.to(dev()), sh.to(dev()), 0.1)
+    z = ops.conv_forward(zg, w.to(dev()), None, 4, 2, 1, False, None, False, 'c', ina)
+    close(z.permute(0, 3, 1, 2), zr.detach(), 2e-5, 2e-5)
+    dw = ops.conv_wgrad(zg, gzd, 4, 2, 1, False, 'c', ina)
+    close(dw, wd.grad, 2e-5, 2e-5 * wd.grad.abs().max().item())
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
