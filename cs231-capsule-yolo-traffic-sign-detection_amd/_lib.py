@@ -20,7 +20,9 @@ class ConvGemm(C.Structure):
                 ('TH', C.c_int), ('TW', C.c_int), ('in_stride', C.c_int), ('dy0', C.c_int), ('dx0', C.c_int),
                 ('dstep', C.c_int),
                 ('Hy', C.c_int), ('Wy', C.c_int), ('out_stride', C.c_int), ('out_oy', C.c_int), ('out_ox', C.c_int),
-                ('act', C.c_int)]
+                ('act', C.c_int),
+                ('bn_z', C.c_void_p), ('bn_scale', C.c_void_p), ('bn_shift', C.c_void_p), ('bn_mean', C.c_void_p),
+                ('bn_invstd', C.c_void_p), ('bn_red', C.c_void_p), ('bn_slope', C.c_float)]
 
 
 class ConvWgrad(C.Structure):

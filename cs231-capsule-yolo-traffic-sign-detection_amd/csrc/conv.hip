@@ -253,6 +253,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
     const int c4 = lane % LPR, rsub = lane / LPR;
     const int n = n0 + wave_n * WC + c4 * 4;
     const bool vec_ok = (a.N & 3) == 0 && (((uintptr_t)a.Y & 15) == 0);
+    const bool bnb = a.bn_red != nullptr && vec_ok && n + 3 < a.N;      // BatchNorm-backward sums of the producer block
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc, b1 = bsc, b2 = bsc;
+    if (bnb) {
+      bsc = *(const f32x4*)(a.bn_scale + n); bsh = *(const f32x4*)(a.bn_shift + n);
+      bmu = *(const f32x4*)(a.bn_mean + n); bis = *(const f32x4*)(a.bn_invstd + n);
+    }
+    f32x4 zq_[64 / RPI];                   // all of this lane's bn_z loads are issued before the first is used
+    if (bnb) {
+#pragma unroll
+      for (int it = 0; it < 64 / RPI; ++it) {
+        const long long off = rowoff[wave_m * 64 + it * RPI + rsub];
+        zq_[it] = *(const f32x4*)(a.bn_z + (off >= 0 ? off : 0) + n);
+      }
+    }
 #pragma unroll
     for (int it = 0; it < 64 / RPI; ++it) {
       const int row_l = it * RPI + rsub;
@@ -263,6 +277,42 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
         else {
 #pragma unroll
           for (int k = 0; k < 4; ++k) if (n + k < a.N) a.Y[off + n + k] = v[k];
+        }
+        if (bnb) {
+          const f32x4 zq = zq_[it];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float y = zq[k] * bsc[k] + bsh[k];
+            const float d = y > 0.f ? v[k] : v[k] * a.bn_slope;
+            b1[k] += d;
+            b2[k] += d * ((zq[k] - bmu[k]) * bis[k]);
+          }
+        }
+      }
+    }
+    if (a.bn_red != nullptr) {             // lanes with the same channel quad (c4): add up the rows they hold
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) { b1[k] += __shfl_xor(b1[k], m, 64); b2[k] += __shfl_xor(b2[k], m, 64); }
+      }
+      __syncthreads();                     // every wave is done with its `ow` slice
+      float* bred = smem;                  // [2 wave_m][BN][2]
+      if (rsub == 0 && bnb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = wave_n * WC + c4 * 4 + k;
+          bred[(wave_m * BN + col) * 2 + 0] = b1[k];
+          bred[(wave_m * BN + col) * 2 + 1] = b2[k];
+        }
+      }
+      __syncthreads();
+      if (t < BN && n0 + t + 0 < a.N && vec_ok) {
+        const int nq = n0 + (t & ~3);
+        if (nq + 3 < a.N) {
+          double* rd = a.bn_red + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.N * 2;
+          atomicAdd(rd + 2 * (n0 + t), (double)bred[t * 2] + (double)bred[(BN + t) * 2]);
+          atomicAdd(rd + 2 * (n0 + t) + 1, (double)bred[t * 2 + 1] + (double)bred[(BN + t) * 2 + 1]);
         }
       }
     }
@@ -653,6 +703,9 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   CY_REQUIRE(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->N > 0 && a->Cin > 0 && a->TH > 0 && a->TW > 0,
              "cy_conv_gemm: non-positive dimension");
   CY_REQUIRE(a->TH * a->TW <= 4096, "cy_conv_gemm: too many taps");
+  CY_REQUIRE(a->bn_red == nullptr || (a->bn_z && a->bn_scale && a->bn_shift && a->bn_mean && a->bn_invstd && a->N % 4 == 0 &&
+                                      (((uintptr_t)a->Y | (uintptr_t)a->bn_z) & 15) == 0),
+             "cy_conv_gemm: bn_red needs bn_z / scale / shift / mean / invstd, N %% 4 == 0 and 16-byte aligned Y, bn_z");
   GemmGeom g;
   g.K = a->TH * a->TW * a->Cin;
   g.KT = (g.K + 31) / 32;

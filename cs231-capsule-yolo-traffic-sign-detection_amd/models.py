@@ -88,11 +88,12 @@ class FusedBackbone(nn.Sequential):
                     defer = ops.s2_fusable(n.k, n.stride, n.padding, m.weight.shape[0], n.weight.shape[0], ho, wo)
                 cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, slope, names[i], defer_act=defer,
                                        in_slope=lazy[2] if lazy is not None else None)
+                cfg.in_holder = lazy[3] if lazy is not None else None
                 out = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
                                      bn.bias if bn is not None else None, cfg,
                                      lazy[0] if lazy is not None else None, lazy[1] if lazy is not None else None)
                 if defer:
-                    x, lazy = out[0], (out[1], out[2], slope)
+                    x, lazy = out[0], (out[1], out[2], slope, getattr(cfg, 'out_holder', None))
                 else:
                     x, lazy = out, None
                 nchw_in = False

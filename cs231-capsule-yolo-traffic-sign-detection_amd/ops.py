@@ -83,6 +83,7 @@ USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 
 
+FUSE_BN_BWD_REDUCE = True  # ... and that block's input-gradient epilogue sums the producer's BatchNorm backward
 FUSE_INPUT_AFFINE = True  # a BN+LeakyReLU block in front of a 4x4/stride-2 block hands over its raw output + scale/shift
 
 
@@ -173,12 +174,16 @@ def dgrad_classes(Hi, Wi, k, stride, pad):
     return out
 
 
-def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
-    """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride."""
+def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv', bn_fuse=None):
+    """dx[B,Hi,Wi,Cin] (NHWC) from dz[B,Ho,Wo,Cout]: one GEMM per output-parity class of the stride.
+    bn_fuse = (z, scale, shift, mean, invstd, slope, red): dx is the gradient with respect to lrelu(z*scale+shift) of the
+    producer block; the epilogues also accumulate that BatchNorm's backward sums into red[STATS_COPIES][Cin][2]."""
     dz, weight = _f32(dz, 'grad'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin = in_shape
     _, Ho, Wo, Cout = dz.shape
     if _winograd_ok(k, stride, pad, Cout, False):
+        if bn_fuse is not None:
+            raise _lib.HipExtensionError('bn_fuse is implemented in the direct input-gradient kernel only')
         return _winograd(dz, weight, None, None, True, tag)
     st = _stream()
     dx = _empty((B, Hi, Wi, Cin), dz)
@@ -191,6 +196,10 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv'):
                      Ho=c['Ho'], Wo=c['Wo'], N=Cin, TH=c['TH'], TW=c['TW'], in_stride=1,
                      dy0=c['dy0'], dx0=c['dx0'], dstep=c['dstep'],
                      Hy=Hi, Wy=Wi, out_stride=c['out_stride'], out_oy=c['out_oy'], out_ox=c['out_ox'], act=0)
+        if bn_fuse is not None:
+            bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
+            a.bn_z, a.bn_scale, a.bn_shift = bz.data_ptr(), bsc.data_ptr(), bsh.data_ptr()
+            a.bn_mean, a.bn_invstd, a.bn_red, a.bn_slope = bmu.data_ptr(), bis.data_ptr(), bred.data_ptr(), float(bsl)
         with timer.range('conv_gemm_dgrad/' + tag):
             call('cy_conv_gemm', C.byref(a), st)
     return dx
@@ -234,6 +243,7 @@ class ConvBlockCfg(object):
         self.k, self.stride, self.pad, self.nchw_in, self.name = k, stride, pad, nchw_in, name
         self.defer_act = defer_act   # return (z, scale, shift): the consumer applies BatchNorm + LeakyReLU on its loads
         self.in_slope = in_slope     # not None: x is the producer's raw output, in_scale / in_shift come with it
+        self.in_holder = None        # the producer's hand-over dict (mean, invstd; this block's backward fills 'red')
         self.bn = bn            # module with running_mean / running_var / momentum / eps / training, or None
         self.slope = slope      # None: no activation; 0.0: ReLU; else LeakyReLU slope
 
@@ -249,6 +259,7 @@ class _ConvBlock(torch.autograd.Function):
         N = weight.shape[0]
         bn = cfg.bn
         ctx.cfg, ctx.has_bias, ctx.bn_train = cfg, bias is not None, False
+        ctx.holder = None
         ina = (in_scale, in_shift, float(cfg.in_slope)) if cfg.in_slope is not None else None
         ctx.in_affine = ina
         if bn is None:
@@ -282,7 +293,11 @@ class _ConvBlock(torch.autograd.Function):
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma)
         if cfg.defer_act:                     # the consumer block applies lrelu(z * scale + shift) on its loads
             ctx.mark_non_differentiable(scale, shift)
+            # hand-over for the backward: the consumer's input-gradient kernel can also produce this block's
+            # BatchNorm-backward sums (it has z and the gradient in registers) and leaves them in holder['red']
+            ctx.holder = cfg.out_holder = {'mean': mean, 'invstd': invstd, 'red': None} if ctx.bn_train else None
             return z, scale, shift
+        ctx.holder = None
         out = torch.empty_like(z)
         call('cy_affine_act', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), slope, P, N, st)
         return out
@@ -311,9 +326,13 @@ class _ConvBlock(torch.autograd.Function):
                 raise _lib.HipExtensionError('backward through an eval-mode BatchNorm block is not implemented')
             scale, shift, mean, invstd, gamma = saved[3:8]
             slope = 1.0 if cfg.slope is None else float(cfg.slope)
-            red = _empty((N, 2), z, torch.float64)
-            call('cy_bn_bwd_reduce', _ptr(z), _ptr(da), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), slope,
-                 _ptr(red), P, N, st)
+            if ctx.holder is not None and ctx.holder.get('red') is not None:
+                red = ctx.holder['red']        # summed by the consumer block's input-gradient epilogues
+                ctx.holder['red'] = None
+            else:
+                red = _empty((N, 2), z, torch.float64)
+                call('cy_bn_bwd_reduce', _ptr(z), _ptr(da), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), slope,
+                     _ptr(red), P, N, st)
             dz = torch.empty_like(z)
             dgamma, dbeta = _empty((N,), z), _empty((N,), z)
             call('cy_bn_bwd_apply', _ptr(z), _ptr(da), _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
@@ -326,7 +345,14 @@ class _ConvBlock(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cfg.nchw_in:
                 raise _lib.HipExtensionError('input gradient of an NCHW-input convolution is not implemented')
-            dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, cfg.name)
+            fuse, h = None, cfg.in_holder
+            if (FUSE_BN_BWD_REDUCE and ctx.in_affine is not None and h is not None and x.shape[3] % 4 == 0
+                    and not _winograd_ok(cfg.k, cfg.stride, cfg.pad, N, False)):
+                bred = torch.zeros((STATS_COPIES, x.shape[3], 2), dtype=torch.float64, device=x.device)
+                fuse = (x, ctx.in_affine[0], ctx.in_affine[1], h['mean'], h['invstd'], ctx.in_affine[2], bred)
+            dx = conv_dgrad(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, cfg.name, fuse)
+            if fuse is not None:
+                h['red'] = bred.sum(0)
         return dx, dW, dbias, dgamma, dbeta, None, None, None
 
 

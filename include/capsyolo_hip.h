@@ -46,6 +46,15 @@ typedef struct {
   int TH, TW, in_stride, dy0, dx0, dstep;
   int Hy, Wy, out_stride, out_oy, out_ox;
   int act;            /* 0 none, 1 ReLU */
+  /* Optional (input-gradient launches): Y is the gradient with respect to lrelu(bn_z * bn_scale + bn_shift), the
+   * activated output of the PRODUCER block whose raw convolution output bn_z has Y's layout.  The epilogue then also
+   * accumulates that BatchNorm's backward sums over the pixels it stores -- per channel n:
+   *   d = Y * (bn_z*scale+shift > 0 ? 1 : bn_slope),  bn_red[copy][n][0] += d,  bn_red[copy][n][1] += d * (bn_z - mean) * invstd
+   * (bn_red[CY_STATS_COPIES][N][2] doubles, zeroed by the caller) -- which replaces the cy_bn_bwd_reduce pass
+   * (loss_fns / autograd of models.py:349-351).  All NULL / 0 when unused. */
+  const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+  double* bn_red;
+  float bn_slope;
 } cy_conv_gemm_t;
 
 /* number of floats of a packed-weight buffer for (K = TH*TW*Cin, N) */

@@ -224,6 +224,30 @@ def test_conv4x4s2_winograd_fused_input_affine(case):
     close(dw, wd.grad, 2e-5, 2e-5 * wd.grad.abs().max().item())
 
 
+@pytest.mark.parametrize('case', [(2, 64, 16, 64, 4, 2, 1), (3, 32, 18, 128, 4, 2, 1), (2, 64, 9, 64, 1, 1, 0)])
+def test_conv_dgrad_epilogue_bn_backward_sums(case):
+    """The input-gradient kernel's optional BatchNorm-backward sums of the producer block (d = dx * lrelu'(y),
+    sum d and sum d * xhat over the pixels it stores, all stride-parity classes together) against cy_bn_bwd_reduce
+    run on the same dx."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import call
+    B, Cin, Hi, Cout, k, stride, pad = case
+    Ho = (Hi + 2 * pad - k) // stride + 1
+    dz = rnd((B, Ho, Ho, Cout), 111).to(dev())
+    w = rnd((Cout, Cin, k, k), 112, 0.1).to(dev())
+    z = rnd((B, Hi, Hi, Cin), 113).to(dev())
+    sc, sh = (rnd((Cin,), 114, 0.3) + 1.0).to(dev()), rnd((Cin,), 115, 0.5).to(dev())
+    mu, isd = rnd((Cin,), 116, 0.2).to(dev()), (rnd((Cin,), 117, 0.1).abs() + 0.8).to(dev())
+    red = torch.zeros((ops.STATS_COPIES, Cin, 2), dtype=torch.float64, device=dev())
+    dx = ops.conv_dgrad(dz, w, (B, Hi, Hi, Cin), k, stride, pad, 'c', (z, sc, sh, mu, isd, 0.1, red))
+    dx0 = ops.conv_dgrad(dz, w, (B, Hi, Hi, Cin), k, stride, pad)
+    assert torch.equal(dx, dx0)
+    ref = torch.zeros((Cin, 2), dtype=torch.float64, device=dev())
+    call('cy_bn_bwd_reduce', z.data_ptr(), dx.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 0.1,
+         ref.data_ptr(), B * Hi * Hi, Cin, torch.cuda.current_stream().cuda_stream)
+    close(red.sum(0), ref, 1e-5, 1e-5)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
