@@ -88,6 +88,7 @@ _SIGS = {
     'cy_yolo_head_fwd': [_P, _P, _L, _I, _I, _P],
     'cy_yolo_head_bwd': [_P, _P, _P, _L, _I, _I, _P],
     'cy_yolo_decode_boxes': [_P, _P, C.c_double, C.c_double, _I, _I, _I, _I, _F, _P, _P, _P, _P, _I, _P],
+    'cy_detect_confusion': [_P, _P, _I, _P, _P, _I, _I, C.c_double, _I, _P, _P],
     'cy_pick_capsule': [_P, _P, _P, _I, _I, _I, _I, _P],
     'cy_adam_multi': [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P],
 }

@@ -85,6 +85,60 @@ __global__ __launch_bounds__(1024) void yolo_decode_kernel(const float* __restri
   if (t == 0) *count = base_s;
 }
 
+// metrics.single_img_confusion (metrics.py:136-147 with calc_iou_individual 99-133) for every image of a batch: one block
+// per image gathers its ground-truth and predicted boxes (decoded by yolo_decode_kernel, sorted by image) into LDS,
+// tests all pairs (IoU in double, like the reference) and counts the boxes that found a partner.
+// out[0..2] += TP, FP, FN; out[3] += malformed boxes (x1 > x2 or y1 > y2: the reference raises on those).
+__global__ __launch_bounds__(256) void detect_confusion_kernel(const int* __restrict__ gt_idx, const double* __restrict__ gt_xy, int n_gt,
+                                                               const int* __restrict__ pr_idx, const double* __restrict__ pr_xy, int n_pr,
+                                                               double iou_th, int max_per_image, int* out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* gxy = sm;                                   // [max_per_image][4]
+  double* pxy = sm + (size_t)max_per_image * 4;       // [max_per_image][4]
+  int* flags = (int*)(pxy + (size_t)max_per_image * 4);   // [2][max_per_image] hit flags
+  __shared__ int cnt[4];
+  const int img = blockIdx.x, t = threadIdx.x;
+  if (t < 4) cnt[t] = 0;
+  __syncthreads();
+  // the boxes of one image are contiguous (np.argwhere order); every thread finds the range by a scan (n is a few
+  // thousand at most)
+  int g0 = n_gt, g1 = 0, p0 = n_pr, p1 = 0;
+  for (int i = 0; i < n_gt; ++i) if (gt_idx[i] == img) { if (i < g0) g0 = i; g1 = i + 1; }
+  for (int i = 0; i < n_pr; ++i) if (pr_idx[i] == img) { if (i < p0) p0 = i; p1 = i + 1; }
+  const int n1 = g1 > g0 ? g1 - g0 : 0, n2 = p1 > p0 ? p1 - p0 : 0;
+  if (n1 > max_per_image || n2 > max_per_image) { if (t == 0) atomicAdd(out + 3, 1 << 20); return; }
+  for (int i = t; i < n1 * 4; i += 256) gxy[i] = gt_xy[(size_t)g0 * 4 + i];
+  for (int i = t; i < n2 * 4; i += 256) pxy[i] = pr_xy[(size_t)p0 * 4 + i];
+  for (int i = t; i < 2 * max_per_image; i += 256) flags[i] = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int i = t; i < n1; i += 256) bad += (gxy[4 * i] > gxy[4 * i + 2]) || (gxy[4 * i + 1] > gxy[4 * i + 3]);
+  for (int j = t; j < n2; j += 256) bad += (pxy[4 * j] > pxy[4 * j + 2]) || (pxy[4 * j + 1] > pxy[4 * j + 3]);
+  if (bad) atomicAdd(&cnt[3], bad);
+  for (int pair = t; pair < n1 * n2; pair += 256) {
+    const int i = pair / n2, j = pair - i * n2;
+    const double x1t = gxy[4 * i], y1t = gxy[4 * i + 1], x2t = gxy[4 * i + 2], y2t = gxy[4 * i + 3];
+    const double x1p = pxy[4 * j], y1p = pxy[4 * j + 1], x2p = pxy[4 * j + 2], y2p = pxy[4 * j + 3];
+    if (x2t < x1p || x2p < x1t || y2t < y1p || y2p < y1t) continue;
+    const double inter = (fmin(x2t, x2p) - fmax(x1t, x1p)) * (fmin(y2t, y2p) - fmax(y1t, y1p));
+    const double iou = inter / ((x2t - x1t) * (y2t - y1t) + (x2p - x1p) * (y2p - y1p) - inter);
+    if (iou > iou_th) { flags[i] = 1; flags[max_per_image + j] = 1; }
+  }
+  __syncthreads();
+  int gh = 0, ph = 0;
+  for (int i = t; i < n1; i += 256) gh += flags[i];
+  for (int j = t; j < n2; j += 256) ph += flags[max_per_image + j];
+  if (gh) atomicAdd(&cnt[0], gh);
+  if (ph) atomicAdd(&cnt[1], ph);
+  __syncthreads();
+  if (t == 0) {
+    atomicAdd(out + 0, cnt[0]);                 // TP = ground-truth boxes hit
+    atomicAdd(out + 1, n2 - cnt[1]);            // FP = predictions that hit nothing
+    atomicAdd(out + 2, n1 - cnt[0]);            // FN
+    if (cnt[3]) atomicAdd(out + 3, cnt[3]);
+  }
+}
+
 // generic 4-D permute: out[b][i1][i2][i3] (contiguous) = in[b*sb + i1*s1 + i2*s2 + i3*s3]
 __global__ void permute4_kernel(const float* __restrict__ in, float* __restrict__ out, long long n, int d1, int d2, int d3,
                                 long long sb, long long s1, long long s2, long long s3, int scatter) {
@@ -227,6 +281,16 @@ extern "C" int cy_yolo_decode_boxes(const float* y, const long long* image_hw, d
   CY_REQUIRE(C == 0 || cls, "cy_yolo_decode_boxes: cls must be given when C > 0");
   yolo_decode_kernel<<<1, 1024, 0, CY_S>>>(y, image_hw, img_h, img_w, B, g, nb, C, conf_th, count, image_idx, xy, cls, max_boxes);
   CY_LAUNCH_CHECK("cy_yolo_decode_boxes");
+  return 0;
+}
+extern "C" int cy_detect_confusion(const int* gt_idx, const double* gt_xy, int n_gt, const int* pr_idx, const double* pr_xy, int n_pr,
+                                   int n_images, double iou_th, int max_per_image, int* out4, void* stream) {
+  CY_REQUIRE(out4 && n_images > 0 && n_gt >= 0 && n_pr >= 0 && max_per_image > 0, "cy_detect_confusion: bad arguments");
+  CY_REQUIRE((n_gt == 0 || (gt_idx && gt_xy)) && (n_pr == 0 || (pr_idx && pr_xy)), "cy_detect_confusion: null box arrays");
+  const size_t lds = (size_t)max_per_image * (8 * 8 + 2 * 4);
+  CY_REQUIRE(lds <= 60 * 1024, "cy_detect_confusion: max_per_image=%d too large", max_per_image);
+  detect_confusion_kernel<<<n_images, 256, lds, CY_S>>>(gt_idx, gt_xy, n_gt, pr_idx, pr_xy, n_pr, iou_th, max_per_image, out4);
+  CY_LAUNCH_CHECK("cy_detect_confusion");
   return 0;
 }
 extern "C" int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,

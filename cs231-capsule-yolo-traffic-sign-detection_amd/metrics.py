@@ -1,0 +1,44 @@
+"""Detection metric of the reference on the device: metrics.detect_acc (metrics.py:245-262).
+
+The reference decodes both arrays to boxes with numpy and matches them with two nested Python loops per image
+(metrics.py:136-147) every `eval_every` epochs; here the decoding (`cy_yolo_decode_boxes`) and the IoU matching
+(`cy_detect_confusion`, one block per image) stay on the GPU and only TP / FP / FN come back.
+"""
+import numpy as np
+import torch
+
+from . import utils
+from ._lib import call
+
+
+def detect_confusion(y, y_hat, params, conf_th=0.5, iou_th=0.5):
+    """(TP, FP, FN) summed over the batch; raises AssertionError on a malformed box like metrics.py:114-119."""
+    n1, gi, gxy, _ = utils.decode_boxes_device(y, params, None, conf_th)
+    n2, pi, pxy, _ = utils.decode_boxes_device(y_hat, params, None, conf_th)
+    batch = int(y.shape[0])
+    g = int(y.shape[1])
+    nb_max = max((int(y.shape[3]) - int(params.n_classes)) // 5, (int(y_hat.shape[3]) - int(params.n_classes)) // 5)
+    out = torch.zeros(4, dtype=torch.int32, device='cuda')
+    call('cy_detect_confusion', gi.data_ptr() if n1 else None, gxy.data_ptr() if n1 else None, n1,
+         pi.data_ptr() if n2 else None, pxy.data_ptr() if n2 else None, n2, batch, float(iou_th), g * g * nb_max,
+         out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    tp, fp, fn, bad = [int(v) for v in out.cpu().numpy()]
+    if bad:
+        raise AssertionError('malformed box (x1 > x2 or y1 > y2) in %d case(s)' % bad)
+    return tp, fp, fn
+
+
+def precision_and_recall(tp, fp, fn):
+    """metrics.py:150-160."""
+    return (tp / (tp + fp) if tp + fp else 0.0), (tp / (tp + fn) if tp + fn else 0.0)
+
+
+def detect_acc(y, y_hat, params):
+    """metrics.py:245-262: F1 of the detector at confidence 0.5 / IoU 0.5."""
+    p, r = precision_and_recall(*detect_confusion(y, y_hat, params))
+    return 2 * p * r / (p + r + 1e-8)
+
+
+def recog_acc(y, y_hat, params):
+    """metrics.py:9-11."""
+    return np.sum(np.asarray(y) == np.argmax(np.asarray(y_hat), axis=1)) / len(y)

@@ -75,10 +75,8 @@ def shuffle(x, y):
     return x[i], y[i]
 
 
-def y_to_boxes_vec(y, params, image_hw=None, conf_th=0.5):
-    """utils.py:288-334 on the device (`cy_yolo_decode_boxes`): y is the network output / ground truth as a numpy
-    array or a tensor, image_hw an optional (batch, 2) array of (height, width).  Returns (image_indices, xy, classes)
-    as numpy arrays like the reference (classes is None when params.n_classes == 0)."""
+def decode_boxes_device(y, params, image_hw=None, conf_th=0.5):
+    """`cy_yolo_decode_boxes` with everything left on the device: (n, image_idx int32[n], xy float64[n,4], cls int32[n] | None)."""
     from ._lib import call
     yt = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device='cuda', dtype=torch.float32).contiguous()
     batch, g, _, D = yt.shape
@@ -98,5 +96,13 @@ def y_to_boxes_vec(y, params, image_hw=None, conf_th=0.5):
          float(conf_th), count.data_ptr(), idx.data_ptr(), xy.data_ptr(), cls.data_ptr() if C else None, cap,
          torch.cuda.current_stream().cuda_stream)
     n = int(count.item())
-    return (idx[:n].cpu().numpy().astype(np.int64), xy[:n].cpu().numpy(),
-            cls[:n].cpu().numpy().astype(np.int64) if C else None)
+    return n, idx[:n], xy[:n], (cls[:n] if C else None)
+
+
+def y_to_boxes_vec(y, params, image_hw=None, conf_th=0.5):
+    """utils.py:288-334 on the device (`cy_yolo_decode_boxes`): y is the network output / ground truth as a numpy
+    array or a tensor, image_hw an optional (batch, 2) array of (height, width).  Returns (image_indices, xy, classes)
+    as numpy arrays like the reference (classes is None when params.n_classes == 0)."""
+    n, idx, xy, cls = decode_boxes_device(y, params, image_hw, conf_th)
+    return (idx.cpu().numpy().astype(np.int64), xy.cpu().numpy(),
+            cls.cpu().numpy().astype(np.int64) if cls is not None else None)

@@ -228,6 +228,13 @@ int cy_yolo_head_bwd(const float* y, const float* dy, float* dx, long long cells
  * *count = number of boxes found (may exceed max_boxes: only the first max_boxes are written). */
 int cy_yolo_decode_boxes(const float* y, const long long* image_hw, double img_h, double img_w, int B, int g, int nb, int C,
                          float conf_th, int* count, int* image_idx, double* xy, int* cls, int max_boxes, void* stream);
+/* Detection metric on the device: metrics.single_img_confusion / calc_iou_individual (metrics.py:99-147) over a
+ * batch.  gt / pr: boxes as cy_yolo_decode_boxes returns them (image index ascending, xy[n][4] double).  Adds to
+ * out4[0..2] TP (ground-truth boxes overlapped by some prediction with IoU > iou_th), FP (predictions that overlap no
+ * ground truth), FN; out4[3] counts malformed boxes (x1 > x2 or y1 > y2; the reference raises AssertionError) and
+ * gets +2^20 per image with more than max_per_image boxes.  The caller zeroes out4. */
+int cy_detect_confusion(const int* gt_idx, const double* gt_xy, int n_gt, const int* pr_idx, const double* pr_xy, int n_pr,
+                        int n_images, double iou_th, int max_per_image, int* out4, void* stream);
 /* torch.gather of the labelled capsule (models.py:122): backward=0: out[B][D] = caps[b][y[b]][:];
  * backward=1: caps is d(out) [B][D], out = d(caps) [B][C][D] (zero off the labelled capsule) */
 int cy_pick_capsule(const float* caps, const long long* y, float* out, int B, int C, int D, int backward, void* stream);

@@ -24,7 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 import capsyolo_amd  # noqa: E402,F401
-from capsyolo_amd import config, dp, synth, utils  # noqa: E402
+from capsyolo_amd import config, dp, metrics, synth, utils  # noqa: E402
 from capsyolo_amd.input_pipeline import DeviceFeeder, quantize_if_exact  # noqa: E402
 from capsyolo_amd.loss_fns import capsule_loss, cnn_loss, dark_loss, darkcapsule_loss  # noqa: E402
 from capsyolo_amd.models import CapsuleNet, ConvNet, DarkCapsuleNet, DarkNet  # noqa: E402
@@ -55,7 +55,7 @@ parser.add_argument('--n_epochs', type=int, default=0, help='override params.jso
 model_loss_predict = {
     'cnn': (ConvNet, cnn_loss, class_pred, None),
     'capsule': (CapsuleNet, capsule_loss, class_pred, None),
-    'darknet_d': (DarkNet, dark_loss, dark_forward, None),
+    'darknet_d': (DarkNet, dark_loss, dark_forward, metrics.detect_acc),          # main.py:261; on the device here
     'darknet_r': (DarkNet, dark_loss, dark_forward, None),
     'darkcapsule': (DarkCapsuleNet, darkcapsule_loss, None, None),
 }
@@ -107,15 +107,22 @@ def train(x, y, model, optimizer, loss_fn, metric, params, bucket):
 
 
 def evaluate(x, y, model, loss_fn, metric, params):
-    """main.py:98-143."""
+    """main.py:98-143 (the metric, when the registry has one, on at most config.max_metric_samples samples)."""
     model.eval()
     n_batch, it = _batches(x, y, params.batch_size)
-    avg_loss = 0.0
+    avg_loss, y_hat, y_true = 0.0, [], []
     with torch.no_grad():
         for x_bch, y_bch in _feed(it, params):
-            _, loss = _forward(model, loss_fn, x_bch, y_bch, params)
+            y_hat_bch, loss = _forward(model, loss_fn, x_bch, y_bch, params)
             avg_loss += loss.item() / n_batch
-    return avg_loss, -1
+            if metric is not None:
+                y_hat.append(y_hat_bch.detach().clone())
+                y_true.append(y_bch.detach().clone())
+    score = -1
+    if metric is not None and y_hat:
+        cap = getattr(config, 'max_metric_samples', 1000)
+        score = float(metric(torch.cat(y_true)[:cap], torch.cat(y_hat)[:cap], params))
+    return avg_loss, score
 
 
 def train_and_evaluate(model, optimizer, loss_fn, metric, params, data, model_dir, restore_file=None):

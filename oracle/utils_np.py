@@ -42,3 +42,45 @@ def y_to_boxes_vec(y, n_classes, darknet_input, image_hw=None, conf_th=0.5):
     if n_classes != 0:
         classes = np.argmax(y[:, :, :, 5 * nb:][indices[:, 0], indices[:, 1], indices[:, 2]], axis=1)
     return image_indices, xy, classes
+
+
+def calc_iou_individual(gt_box, pred_box):
+    """metrics.py:99-133 (a malformed box raises, like the reference)."""
+    x1_t, y1_t, x2_t, y2_t = gt_box
+    x1_p, y1_p, x2_p, y2_p = pred_box
+    if (x1_p > x2_p) or (y1_p > y2_p) or (x1_t > x2_t) or (y1_t > y2_t):
+        raise AssertionError('malformed box')
+    if x2_t < x1_p or x2_p < x1_t or y2_t < y1_p or y2_p < y1_t:
+        return 0.0
+    inter = (min(x2_t, x2_p) - max(x1_t, x1_p)) * (min(y2_t, y2_p) - max(y1_t, y1_p))
+    return inter / ((x2_t - x1_t) * (y2_t - y1_t) + (x2_p - x1_p) * (y2_p - y1_p) - inter)
+
+
+def single_img_confusion(y_, y_hat_, iou_th):
+    """metrics.py:136-147: a ground-truth / predicted box counts as hit when ANY partner overlaps it by more than iou_th."""
+    n1, n2 = y_.shape[0], y_hat_.shape[0]
+    gt_hit, pred_hit = set(), set()
+    for i in range(n1):
+        for j in range(n2):
+            if calc_iou_individual(y_[i], y_hat_[j]) > iou_th:
+                gt_hit.add(i)
+                pred_hit.add(j)
+    return len(gt_hit), n2 - len(pred_hit), n1 - len(gt_hit)
+
+
+def detect_confusion(y, y_hat, darknet_input, conf_th=0.5, iou_th=0.5):
+    """TP, FP, FN of metrics.py:245-258 (n_classes = 0: detector head)."""
+    yi, yb, _ = y_to_boxes_vec(y, 0, darknet_input, conf_th=conf_th)
+    hi, hb, _ = y_to_boxes_vec(y_hat, 0, darknet_input, conf_th=conf_th)
+    tot = np.zeros(3, dtype=np.int64)
+    for j in range(y.shape[0]):
+        tot += np.array(single_img_confusion(yb[yi == j], hb[hi == j], iou_th))
+    return tot
+
+
+def detect_acc(y, y_hat, darknet_input):
+    """metrics.py:245-262: F1 of the detector."""
+    tp, fp, fn = [int(v) for v in detect_confusion(y, y_hat, darknet_input)]
+    p = tp / (tp + fp) if tp + fp else 0.0
+    r = tp / (tp + fn) if tp + fn else 0.0
+    return 2 * p * r / (p + r + 1e-8)

@@ -530,3 +530,23 @@ def test_y_to_boxes_vec_device_matches_reference(tag):
         assert np.array_equal(cls, gold[tag + '_cls'])
     else:
         assert cls is None
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_detect_acc_device_matches_reference(tag):
+    """Device-side decode + IoU matching (cy_yolo_decode_boxes, cy_detect_confusion) against the reference's
+    metrics.detect_acc and its TP / FP / FN."""
+    import types
+    from capsyolo_amd import metrics
+    from helpers import load_golden
+    from test_oracle_golden import _detect_case
+    gold = load_golden('metrics')
+    seed, B, g, nb = [int(v) for v in gold[tag + '_cfg']]
+    y, y_hat = _detect_case(seed, B, g, nb)
+    p = types.SimpleNamespace(n_classes=0, darknet_input=416)
+    assert list(metrics.detect_confusion(y, y_hat, p)) == [int(v) for v in gold[tag + '_tpfpfn']]
+    assert abs(metrics.detect_acc(y, y_hat, p) - float(gold[tag + '_f1'])) < 1e-15
+    bad = y_hat.copy()
+    bad[0, 0, 0, 0], bad[0, 0, 0, 3] = 0.9, -0.2              # negative width: x1 > x2
+    with pytest.raises(AssertionError):
+        metrics.detect_confusion(y, bad, p)

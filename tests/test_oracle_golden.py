@@ -278,3 +278,32 @@ def test_y_to_boxes_vec_oracle_matches_reference(tag):
         assert np.array_equal(cls, gold[tag + '_cls'])
     else:
         assert cls is None
+
+
+def _detect_case(seed, B, g, nb):
+    rng = np.random.default_rng(seed)
+    y = np.zeros((B, g, g, 5), dtype=np.float64)
+    mark = rng.random((B, g, g)) < 0.25
+    y[..., 0] = mark
+    y[..., 1:3] = rng.random((B, g, g, 2)) * mark[..., None]
+    y[..., 3:5] = (0.05 + 0.3 * rng.random((B, g, g, 2))) * mark[..., None]
+    y_hat = rng.random((B, g, g, 5 * nb)).astype(np.float32)
+    y_hat[..., 0::5] *= 0.55
+    for k in range(nb):
+        jit = 1.0 + 0.25 * (rng.random((B, g, g, 4)) - 0.5)
+        take = mark & (rng.random((B, g, g)) < 0.7)
+        y_hat[..., 5 * k + 1:5 * k + 5] = np.where(take[..., None], y[..., 1:5] * jit, y_hat[..., 5 * k + 1:5 * k + 5])
+        y_hat[..., 5 * k] = np.where(take, 0.9, y_hat[..., 5 * k])
+    y_hat[..., 3::5] = np.abs(y_hat[..., 3::5]); y_hat[..., 4::5] = np.abs(y_hat[..., 4::5])
+    return y, y_hat
+
+
+@pytest.mark.parametrize('tag', ['a', 'b', 'c'])
+def test_detect_acc_oracle_matches_reference(tag):
+    """oracle/utils_np.detect_confusion / detect_acc against the reference's metrics.detect_acc (metrics.py:245-262)."""
+    from oracle import utils_np
+    gold = load_golden('metrics')
+    seed, B, g, nb = [int(v) for v in gold[tag + '_cfg']]
+    y, y_hat = _detect_case(seed, B, g, nb)
+    assert np.array_equal(utils_np.detect_confusion(y, y_hat, 416), gold[tag + '_tpfpfn'])
+    assert utils_np.detect_acc(y, y_hat, 416) == float(gold[tag + '_f1'])
