@@ -852,6 +852,8 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv3x3_winograd: bad arguments");
   CY_REQUIRE(Cin % KC == 0 && Cin >= KC, "cy_conv3x3_winograd: Cin=%d must be a multiple of %d", Cin, KC);
   CY_REQUIRE((((uintptr_t)X | (uintptr_t)U) & 15) == 0, "cy_conv3x3_winograd: operands must be 16-byte aligned");
+  CY_REQUIRE((long long)H * W * Cin < (1ll << 29) && (long long)H * W * Cout < (1ll << 29),
+             "cy_conv3x3_winograd: image too large for 32-bit byte offsets");
   WinoArgs a;
   a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
@@ -880,6 +882,8 @@ extern "C" int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float*
   CY_REQUIRE(X && dZ && dW && ws && B > 0 && H > 0 && W > 0, "cy_conv3x3_winograd_wgrad: bad arguments");
   CY_REQUIRE(Cin % 64 == 0 && Cout % 64 == 0, "cy_conv3x3_winograd_wgrad: Cin=%d and Cout=%d must be multiples of 64", Cin, Cout);
   CY_REQUIRE((((uintptr_t)X | (uintptr_t)dZ) & 15) == 0, "cy_conv3x3_winograd_wgrad: operands must be 16-byte aligned");
+  CY_REQUIRE((long long)H * W * Cin < (1ll << 29) && (long long)H * W * Cout < (1ll << 29),
+             "cy_conv3x3_winograd_wgrad: image too large for 32-bit byte offsets");
   WinoWgradArgs a;
   a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.gh = (H + 3) / 4; a.gw = (W + 7) / 8;
