@@ -11,10 +11,8 @@ from . import utils
 from ._lib import call
 
 
-def detect_confusion(y, y_hat, params, conf_th=0.5, iou_th=0.5):
-    """(TP, FP, FN) summed over the batch; raises AssertionError on a malformed box like metrics.py:114-119."""
-    n1, gi, gxy, _ = utils.decode_boxes_device(y, params, None, conf_th)
-    n2, pi, pxy, _ = utils.decode_boxes_device(y_hat, params, None, conf_th)
+def _confusion_of_boxes(gt, pr, y, y_hat, params, iou_th):
+    (n1, gi, gxy, _), (n2, pi, pxy, _) = gt, pr
     batch = int(y.shape[0])
     g = int(y.shape[1])
     nb_max = max((int(y.shape[3]) - int(params.n_classes)) // 5, (int(y_hat.shape[3]) - int(params.n_classes)) // 5)
@@ -26,6 +24,12 @@ def detect_confusion(y, y_hat, params, conf_th=0.5, iou_th=0.5):
     if bad:
         raise AssertionError('malformed box (x1 > x2 or y1 > y2) in %d case(s)' % bad)
     return tp, fp, fn
+
+
+def detect_confusion(y, y_hat, params, conf_th=0.5, iou_th=0.5):
+    """(TP, FP, FN) summed over the batch; raises AssertionError on a malformed box like metrics.py:114-119."""
+    return _confusion_of_boxes(utils.decode_boxes_device(y, params, None, conf_th),
+                               utils.decode_boxes_device(y_hat, params, None, conf_th), y, y_hat, params, iou_th)
 
 
 def precision_and_recall(tp, fp, fn):
@@ -42,3 +46,27 @@ def detect_acc(y, y_hat, params):
 def recog_acc(y, y_hat, params):
     """metrics.py:9-11."""
     return np.sum(np.asarray(y) == np.argmax(np.asarray(y_hat), axis=1)) / len(y)
+
+
+def average_precision(p, r):
+    """metrics.py:180-190: 11-point interpolated average precision."""
+    out = []
+    for level in np.linspace(0.0, 1.0, 11):
+        args = np.argwhere(r >= level).flatten()
+        out.append(max(p[args]) if len(args) else 0.0)
+    return np.mean(out)
+
+
+def detect_AP(y, y_hat, params, show=False, save=False, save_dir=None):
+    """metrics.py:193-243 (plots are out of scope): boxes are decoded once per confidence threshold and matched on the
+    device for each of the 10 IoU thresholds."""
+    iou_ths, conf_ths = np.linspace(0.5, 0.95, 10), np.linspace(0, 1, 100)
+    yt = torch.as_tensor(np.asarray(y) if not torch.is_tensor(y) else y).to(device='cuda', dtype=torch.float32)
+    ht = torch.as_tensor(np.asarray(y_hat) if not torch.is_tensor(y_hat) else y_hat).to(device='cuda', dtype=torch.float32)
+    prec, rec = np.zeros((10, 100)), np.zeros((10, 100))
+    for k, conf_th in enumerate(conf_ths):
+        gt = utils.decode_boxes_device(yt, params, None, conf_th)
+        pr = utils.decode_boxes_device(ht, params, None, conf_th)
+        for i, iou_th in enumerate(iou_ths):
+            prec[i, k], rec[i, k] = precision_and_recall(*_confusion_of_boxes(gt, pr, yt, ht, params, iou_th))
+    return np.mean(np.array([average_precision(prec[i], rec[i]) for i in range(10)]))

@@ -84,3 +84,25 @@ def detect_acc(y, y_hat, darknet_input):
     p = tp / (tp + fp) if tp + fp else 0.0
     r = tp / (tp + fn) if tp + fn else 0.0
     return 2 * p * r / (p + r + 1e-8)
+
+
+def average_precision(p, r):
+    """metrics.py:180-190: 11-point interpolated average precision."""
+    out = []
+    for level in np.linspace(0.0, 1.0, 11):
+        args = np.argwhere(r >= level).flatten()
+        out.append(max(p[args]) if len(args) else 0.0)
+    return np.mean(out)
+
+
+def detect_AP(y, y_hat, darknet_input):
+    """metrics.py:193-243 without the plotting: mean over 10 IoU thresholds of the 11-point AP over 100 confidence thresholds."""
+    aps = []
+    for iou_th in np.linspace(0.5, 0.95, 10):
+        ps, rs = [], []
+        for conf_th in np.linspace(0, 1, 100):
+            tp, fp, fn = [int(v) for v in detect_confusion(y, y_hat, darknet_input, conf_th, iou_th)]
+            ps.append(tp / (tp + fp) if tp + fp else 0.0)
+            rs.append(tp / (tp + fn) if tp + fn else 0.0)
+        aps.append(average_precision(np.array(ps), np.array(rs)))
+    return np.mean(np.array(aps))

@@ -546,6 +546,8 @@ def test_detect_acc_device_matches_reference(tag):
     p = types.SimpleNamespace(n_classes=0, darknet_input=416)
     assert list(metrics.detect_confusion(y, y_hat, p)) == [int(v) for v in gold[tag + '_tpfpfn']]
     assert abs(metrics.detect_acc(y, y_hat, p) - float(gold[tag + '_f1'])) < 1e-15
+    if tag + '_ap' in gold.files:
+        assert abs(metrics.detect_AP(y, y_hat, p) - float(gold[tag + '_ap'])) < 1e-12
     bad = y_hat.copy()
     bad[0, 0, 0, 0], bad[0, 0, 0, 3] = 0.9, -0.2              # negative width: x1 > x2
     with pytest.raises(AssertionError):

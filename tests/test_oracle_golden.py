@@ -307,3 +307,5 @@ def test_detect_acc_oracle_matches_reference(tag):
     y, y_hat = _detect_case(seed, B, g, nb)
     assert np.array_equal(utils_np.detect_confusion(y, y_hat, 416), gold[tag + '_tpfpfn'])
     assert utils_np.detect_acc(y, y_hat, 416) == float(gold[tag + '_f1'])
+    if tag == 'c':
+        assert utils_np.detect_AP(y, y_hat, 416) == float(gold[tag + '_ap'])
