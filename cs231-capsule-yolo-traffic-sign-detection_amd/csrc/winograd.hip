@@ -66,31 +66,35 @@ constexpr int wino_use(int xi) { return 8 * (xi >> 1) + (xi & 1); }
 constexpr int wino_issue(int xi) { return wino_use(xi) - 8; }              // < 0: fetched before the loop body
 constexpr int wino_frag_pos(int s) { return ((s & 7) < 2 && s + 8 < 64) ? wino_xi(s) + 2 : -1; }   // position prefetched in slot s
 // side work, one piece per slot (see the slot body):
-//   1 S_U   U(c+1) registers -> LDS (2 pieces)      7 S_raw  patch of chunk c+2 registers -> LDS (3)
+//   1 S_U   U(c+1) registers -> LDS, one float4 per piece (8)      7 S_raw  patch of chunk c+2 registers -> LDS (3)
 //   2 G_raw patch loads of chunk c+3 (3), right after their registers were stored: a whole chunk of latency cover
 //   3 G_U   U loads of c+2 (8)
 //   4 T_rd  patch of chunk c+1 from LDS, two float2 per piece, rows in the order 1,2,0,3 (8)
-//   5 T_v   one row of V = B^T d B: 8 packed adds + 4 LDS writes (4, rows in the order 1,2,0,3)
+//   5 T_v   half a row of V = B^T d B: 5 packed adds + 2 LDS writes (8, rows in the order 1,2,0,3)
 // pieces of different kinds are interleaved and the loads spread out: 11 global loads in consecutive slots back up
 // the CU's one vector-memory pipeline (a patch load touches 32 cache lines) and the stalled wave stops issuing MFMAs
 constexpr int wino_find(const int* list, int n, int s) {
   for (int i = 0; i < n; ++i) if (list[i] == s) return i;
   return -1;
 }
-constexpr int WS_SU[2] = {0, 1};
-constexpr int WS_GU[8] = {2, 4, 6, 10, 12, 14, 18, 20};
-constexpr int WS_TRD[8] = {3, 5, 7, 11, 13, 15, 19, 21};
-constexpr int WS_TV[4] = {23, 27, 29, 31};
-constexpr int WS_SRAW[3] = {34, 36, 38};
-constexpr int WS_GRAW[3] = {42, 44, 46};
+// LDS WRITE bandwidth is the scarce resource of the chunk (U 32 KB + patch 10 KB + V 32 KB per chunk against ~70 B/clk/CU:
+// s_memtime stamps showed the 8 back-to-back U stores of all four waves holding the first four slots for 600 extra
+// cycles, every 4-store V row for 100-200): every piece stores at most 2 x 512 B or 1 x 1 KB per wave, and store pieces
+// alternate with pieces that do not store.
+constexpr int WS_SRAW[3] = {2, 3, 4};
+constexpr int WS_GRAW[3] = {5, 6, 7};
+constexpr int WS_SU[8] = {10, 11, 12, 13, 14, 15, 18, 19};
+constexpr int WS_GU[8] = {20, 22, 26, 28, 30, 34, 36, 38};
+constexpr int WS_TRD[8] = {21, 23, 27, 29, 31, 35, 37, 39};
+constexpr int WS_TV[8] = {42, 43, 44, 45, 46, 47, 50, 51};
 constexpr int wino_side_kind(int s) {
-  return wino_find(WS_SU, 2, s) >= 0 ? 1 : wino_find(WS_GRAW, 3, s) >= 0 ? 2 : wino_find(WS_GU, 8, s) >= 0 ? 3
-       : wino_find(WS_TRD, 8, s) >= 0 ? 4 : wino_find(WS_TV, 4, s) >= 0 ? 5 : wino_find(WS_SRAW, 3, s) >= 0 ? 7 : 0;
+  return wino_find(WS_SU, 8, s) >= 0 ? 1 : wino_find(WS_GRAW, 3, s) >= 0 ? 2 : wino_find(WS_GU, 8, s) >= 0 ? 3
+       : wino_find(WS_TRD, 8, s) >= 0 ? 4 : wino_find(WS_TV, 8, s) >= 0 ? 5 : wino_find(WS_SRAW, 3, s) >= 0 ? 7 : 0;
 }
 constexpr int wino_side_idx(int s) {
   const int k = wino_side_kind(s);
-  return k == 1 ? wino_find(WS_SU, 2, s) : k == 2 ? wino_find(WS_GRAW, 3, s) : k == 3 ? wino_find(WS_GU, 8, s)
-       : k == 4 ? wino_find(WS_TRD, 8, s) : k == 5 ? wino_find(WS_TV, 4, s) : k == 7 ? wino_find(WS_SRAW, 3, s) : 0;
+  return k == 1 ? wino_find(WS_SU, 8, s) : k == 2 ? wino_find(WS_GRAW, 3, s) : k == 3 ? wino_find(WS_GU, 8, s)
+       : k == 4 ? wino_find(WS_TRD, 8, s) : k == 5 ? wino_find(WS_TV, 8, s) : k == 7 ? wino_find(WS_SRAW, 3, s) : 0;
 }
 constexpr int wino_row_order(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 0 : 3; }
 constexpr int wino_side_lds(int s) {
@@ -98,7 +102,7 @@ constexpr int wino_side_lds(int s) {
   // a LOWER bound of the LDS instructions the slot issues (the waits below may never allow more outstanding
   // operations than are really younger): two float2 reads may merge into one ds_read2_b64, the last S_raw store
   // is exec-masked and may be skipped by a whole wave
-  return (k == 1 || k == 5) ? 4 : (k == 4) ? 1 : (k == 7 && wino_side_idx(s) < 2) ? 1 : 0;
+  return k == 1 ? 1 : k == 5 ? 2 : (k == 4) ? 1 : (k == 7 && wino_side_idx(s) < 2) ? 1 : 0;
 }
 constexpr int wino_frag_lds(int s) { return wino_frag_pos(s) >= 0 ? 2 : 0; }
 // LDS operations younger than position xi's fragments when its first MFMA issues (s_waitcnt lgkmcnt operand)
@@ -242,6 +246,20 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
     *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[1], t0[3]);
   };
+  auto Vhalf = [&](float* vb, int R, int jp) {   // columns 2 jp, 2 jp + 1 of row R
+    f32x2 t0[4];
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      t0[cc] = R == 0 ? pk_sub(xv[0][cc], xv[2][cc]) : R == 1 ? pk_add(xv[1][cc], xv[2][cc])
+             : R == 2 ? pk_sub(xv[2][cc], xv[1][cc]) : pk_sub(xv[1][cc], xv[3][cc]);
+    if (jp == 0) {
+      *(f32x2*)(vb + (R * 4 + 0) * 2 * SLAB) = pk_sub(t0[0], t0[2]);
+      *(f32x2*)(vb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[1], t0[2]);
+    } else {
+      *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
+      *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[1], t0[3]);
+    }
+  };
   auto T = [&](int c) {                     // raw patch -> V (this thread's tile, 2 channels)
     const float* rb = Rs + (c & 1) * RAW_BUF + tbase;
 #pragma unroll
@@ -324,9 +342,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
         fb_[fq & 3] = *(const f32x4*)(ub_ + fq * 2 * SLAB);                                         \
       }                                                                                             \
       constexpr int kind = wino_side_kind(sidx), k_ = wino_side_idx(sidx);                          \
-      if (kind == 1) {                      /* U(c+1): registers -> LDS, 4 float4 per piece */     \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q)                                               \
-          *(f32x4*)(uw_ + (k_ * 4 + q) * 4 * SLAB) = gu[k_ * 4 + q];                                \
+      if (kind == 1) {                      /* U(c+1): registers -> LDS, one float4 per piece */   \
+        *(f32x4*)(uw_ + k_ * 4 * SLAB) = gu[k_];                                                    \
       } else if (kind == 2) {               /* patch loads of chunk c+3 */                         \
         if (blk_fast) {                                                                             \
           graw[k_] = *(const f32x4*)(gxfast + gvoff[k_]);                                           \
@@ -340,8 +357,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
         constexpr int r_ = wino_row_order((k_ >> 1) & 3), c0_ = 2 * (k_ & 1);                       \
         xv[r_][c0_] = *(const f32x2*)(rb_ + (r_ * 18 + c0_) * 4);                                   \
         xv[r_][c0_ + 1] = *(const f32x2*)(rb_ + (r_ * 18 + c0_ + 1) * 4);                           \
-      } else if (kind == 5) {               /* one row of V */                                     \
-        Vrow(vw_, wino_row_order(k_ & 3));                                                          \
+      } else if (kind == 5) {               /* half a row of V */                                  \
+        Vhalf(vw_, wino_row_order((k_ >> 1) & 3), k_ & 1);                                          \
       } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
         if (k_ < 2) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                           \
         else if (roff[k_] >= 0) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                               \
