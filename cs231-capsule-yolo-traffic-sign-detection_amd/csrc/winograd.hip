@@ -542,27 +542,30 @@ struct WinoWgradArgs {
 
 // Side work of one chunk, one piece per MFMA slot:
 //   2 T    raw-patch reads of chunk c+1, two ds_read2st64_b32 per piece: dY first, then input rows 1,2,0,3   (10 pieces)
-//   5 Z    one row of G dY G^T for both tiles                                                                (4 pieces)
-//   4 V    one row of B^T d B for both tiles, rows in the order 1,2,0,3                                       (4 pieces)
+//   5 Z    half a row of G dY G^T for both tiles (at most 2 LDS stores per slot)                             (8 pieces)
+//   4 V    half a row of B^T d B for both tiles, rows in the order 1,2,0,3                                    (8 pieces)
 //   6      barrier: every wave is past its raw-patch reads
 //   7 S    one float4 of chunk c+2 registers -> raw LDS                                                       (6 pieces)
 //   1 G    one global load of chunk c+3 (almost a whole chunk of latency cover, one register set)             (6 pieces)
+constexpr int WG_T[10] = {2, 3, 4, 5, 6, 7, 10, 11, 12, 13};
+constexpr int WG_Z[8] = {14, 15, 18, 19, 20, 21, 22, 23};          // half rows: at most 2 LDS stores per slot (winograd forward)
+constexpr int WG_V[8] = {26, 27, 28, 29, 30, 31, 34, 35};
+constexpr int WG_BAR = 36;
+constexpr int WG_S[6] = {37, 38, 39, 42, 43, 44};
+constexpr int WG_G[6] = {45, 46, 47, 50, 51, 52};
 constexpr int wg_side_kind(int s) {
-  if ((s >= 2 && s < 8) || (s >= 10 && s < 14)) return 2;
-  if (s == 14 || s == 15 || s == 18 || s == 19) return 5;
-  if (s >= 20 && s < 24) return 4;
-  if (s == 27) return 6;
-  if ((s >= 28 && s < 32) || s == 34 || s == 35) return 7;
-  if (s >= 36 && s < 42) return 1;
-  return 0;
+  return wino_find(WG_T, 10, s) >= 0 ? 2 : wino_find(WG_Z, 8, s) >= 0 ? 5 : wino_find(WG_V, 8, s) >= 0 ? 4 : s == WG_BAR ? 6
+       : wino_find(WG_S, 6, s) >= 0 ? 7 : wino_find(WG_G, 6, s) >= 0 ? 1 : 0;
 }
 constexpr int wg_side_idx(int s) {
-  return s < 8 ? s - 2 : s < 14 ? s - 4 : s < 16 ? s - 14 : s < 20 ? s - 16 : s < 24 ? s - 20 : s < 32 ? s - 28 : s < 36 ? s - 30 : s - 36;
+  const int k = wg_side_kind(s);
+  return k == 2 ? wino_find(WG_T, 10, s) : k == 5 ? wino_find(WG_Z, 8, s) : k == 4 ? wino_find(WG_V, 8, s)
+       : k == 7 ? wino_find(WG_S, 6, s) : k == 1 ? wino_find(WG_G, 6, s) : 0;
 }
 constexpr int wg_row_order(int i) { return i == 0 ? 1 : i == 1 ? 2 : i == 2 ? 0 : 3; }
 constexpr int wg_side_lds(int s) {          // LOWER bound of the LDS instructions issued by the slot
   const int k = wg_side_kind(s);
-  return k == 2 ? 2 : k == 4 ? 4 : k == 5 ? 4 : k == 7 ? 1 : 0;
+  return k == 2 ? 2 : k == 4 ? 2 : k == 5 ? 2 : k == 7 ? 1 : 0;
 }
 constexpr int wg_younger(int xi) {
   const int is = wino_issue(xi), us = wino_use(xi);
@@ -701,6 +704,33 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
     *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[3], t0[1]);
   };
+  auto Vhalf = [&](float* vb, int R, int jp) {   // columns 2 jp, 2 jp + 1 of row R
+    f32x2 t0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      t0[c] = R == 0 ? pk_sub(xv[0][c], xv[2][c]) : R == 1 ? pk_add(xv[1][c], xv[2][c])
+            : R == 2 ? pk_sub(xv[2][c], xv[1][c]) : pk_sub(xv[3][c], xv[1][c]);
+    if (jp == 0) {
+      *(f32x2*)(vb + (R * 4 + 0) * 2 * SLAB) = pk_sub(t0[0], t0[2]);
+      *(f32x2*)(vb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[1], t0[2]);
+    } else {
+      *(f32x2*)(vb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[2], t0[1]);
+      *(f32x2*)(vb + (R * 4 + 3) * 2 * SLAB) = pk_sub(t0[3], t0[1]);
+    }
+  };
+  auto Zhalf = [&](float* zb, int R, int jp) {
+    f32x2 t0[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+      t0[c] = R == 0 ? zv[0][c] : R == 1 ? pk_add(zv[0][c], zv[1][c]) : R == 2 ? pk_sub(zv[0][c], zv[1][c]) : zv[1][c];
+    if (jp == 0) {
+      *(f32x2*)(zb + (R * 4 + 0) * 2 * SLAB) = t0[0];
+      *(f32x2*)(zb + (R * 4 + 1) * 2 * SLAB) = pk_add(t0[0], t0[1]);
+    } else {
+      *(f32x2*)(zb + (R * 4 + 2) * 2 * SLAB) = pk_sub(t0[0], t0[1]);
+      *(f32x2*)(zb + (R * 4 + 3) * 2 * SLAB) = t0[1];
+    }
+  };
   auto Zrow = [&](float* zb, int R) {       // row R of (2G) dY (2G)^T
     f32x2 t0[2];
 #pragma unroll
@@ -781,10 +811,10 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
         }                                                                                           \
       } else if (kind == 4) {               /* all patch reads are >= 14 LDS operations old */     \
         if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (14 << 8));                                \
-        Vrow(vw_, wg_row_order(k_ & 3));                                                            \
+        Vhalf(vw_, wg_row_order((k_ >> 1) & 3), k_ & 1);                                            \
       } else if (kind == 5) {               /* the dY reads are >= 14 LDS operations old */        \
         if (k_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (14 << 8));                                \
-        Zrow(zw_, k_ & 3);                                                                          \
+        Zhalf(zw_, (k_ >> 1) & 3, k_ & 1);                                                          \
       } else if (kind == 6) {               /* all waves are past their raw-patch reads */         \
         __builtin_amdgcn_s_barrier();                                                               \
       } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
