@@ -538,6 +538,8 @@ constexpr int RAWW_BUF = (XPS + ZP) * 64;   // floats: [pixel][64 channels] for 
 struct WinoWgradArgs {
   const float* X; const float* dZ; float* slab;
   int B, H, W, Cin, Cout, gh, gw;           // gh x gw tile groups per image
+  int nrange;                               // the B * gh * gw tile groups are cut into nrange contiguous ranges, one block (and one
+                                            // partial-sum slab) per range and (ci, co) tile: ~one block per CU for any batch / map size
 };
 
 // Side work of one chunk, one piece per MFMA slot:
@@ -608,13 +610,17 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
   if ((gridDim.x & 7) == 0) vid = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int cob = vid % ncb;
   const int cib = (vid / ncb) % nib;
-  const int b = vid / (ncb * nib);
-  const int nchunk = a.gh * a.gw;
+  const int jr = vid / (ncb * nib);         // range of tile groups
+  const int ngroups = a.gh * a.gw;
+  const long long gtot = (long long)a.B * ngroups;
+  const int cbeg = (int)(gtot * jr / a.nrange), cend = (int)(gtot * (jr + 1) / a.nrange);
+  const int nchunk = cend - cbeg;           // >= 1 (nrange <= B * ngroups)
 
   // ---- loader: raw items (pixel = prow + 16 q, float4 column c4): 4 input + 2 dY float4 per thread
   const int c4 = t & 15, prow = t >> 4;
-  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin + cib * 64);      // uniform
-  const char* zimg = (const char*)(a.dZ + (long long)b * a.H * a.W * a.Cout + cob * 64);    // uniform
+  const char* xall = (const char*)(a.X + cib * 64);          // + image * ximgb (uniform)
+  const char* zall = (const char*)(a.dZ + cob * 64);
+  const size_t ximgb = (size_t)a.H * a.W * a.Cin * 4, zimgb = (size_t)a.H * a.W * a.Cout * 4;
   int xpy[4], xpx[4];
   unsigned voffx[4], voffz[2];              // byte offsets of this thread's items from the patch origin
 #pragma unroll
@@ -635,7 +641,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
   auto is_fast = [&](int gy, int gxx) {
     return gy > 0 && gxx > 0 && gy * 4 + 5 <= a.H && gxx * 8 + 9 <= a.W;
   };
-  auto Gx = [&](int q, int gy, int gxx, bool fast) {
+  auto Gx = [&](int q, int gb, int gy, int gxx, bool fast) {
+    const char* ximg = xall + gb * ximgb;
     const int iy0 = gy * 4 - 1, ix0 = gxx * 8 - 1;
     if (fast) {
       gx[q] = *(const f32x4*)(ximg + (size_t)((iy0 * a.W + ix0) * a.Cin) * 4 + voffx[q]);
@@ -646,7 +653,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
       okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
     }
   };
-  auto Gz = [&](int q, int gy, int gxx, bool fast) {
+  auto Gz = [&](int q, int gb, int gy, int gxx, bool fast) {
+    const char* zimg = zall + gb * zimgb;
     if (fast) {
       gz[q] = *(const f32x4*)(zimg + (size_t)((gy * 4 * a.W + gxx * 8) * a.Cout) * 4 + voffz[q]);
     } else {
@@ -668,12 +676,13 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     else *(f32x4*)dst = (okm >> (4 + q)) & 1 ? gz[q] : f32x4{0.f, 0.f, 0.f, 0.f};
   };
   auto Gall = [&](int c) {
-    const int gy = c / a.gw, gxx = c - gy * a.gw;
+    const int gb = (cbeg + c) / ngroups, gr = (cbeg + c) - gb * ngroups;
+    const int gy = gr / a.gw, gxx = gr - gy * a.gw;
     const bool fast = is_fast(gy, gxx);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Gx(q, gy, gxx, fast);
+    for (int q = 0; q < 4; ++q) Gx(q, gb, gy, gxx, fast);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) Gz(q, gy, gxx, fast);
+    for (int q = 0; q < 2; ++q) Gz(q, gb, gy, gxx, fast);
     gfast = fast;
   };
   auto Sall = [&]() {
@@ -775,8 +784,9 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     const float* ub_ = Zs + (c & 1) * VU_BUF + fragB;
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // T(c+1) (harmless after the last chunk)
     float* zw_ = Zs + ((c + 1) & 1) * VU_BUF + vdst;
-    const int cg = (c + 3 < nchunk) ? c + 3 : nchunk - 1;
-    const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
+    const int cg = cbeg + ((c + 3 < nchunk) ? c + 3 : nchunk - 1);
+    const int ggb = cg / ngroups, ggr = cg - ggb * ngroups;
+    const int ggy = ggr / a.gw, ggx = ggr - ggy * a.gw;
     const bool gf_next = is_fast(ggy, ggx);
     f32x4 fa_[4], fb_[4];
     fa_[0] = *(const f32x4*)(vb_);
@@ -797,7 +807,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
       }                                                                                             \
       constexpr int kind = wg_side_kind(sidx), k_ = wg_side_idx(sidx) >= 0 ? wg_side_idx(sidx) : 0; \
       if (kind == 1) {                      /* one global load of chunk c+3 */                     \
-        if (k_ < 4) Gx(k_ & 3, ggy, ggx, gf_next); else Gz(k_ & 1, ggy, ggx, gf_next);              \
+        if (k_ < 4) Gx(k_ & 3, ggb, ggy, ggx, gf_next); else Gz(k_ & 1, ggb, ggy, ggx, gf_next);              \
         if (k_ == 5) gfast = gf_next;                                                               \
       } else if (kind == 2) {               /* raw patches of chunk c+1: 2 pairs */                \
         if (k_ < 2) {                                                                               \
@@ -832,7 +842,7 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
   }
 
   // ---- per-image partial dU[xi][ci][co] -> slab[b]
-  float* out = a.slab + ((long long)b * 16) * a.Cin * a.Cout;
+  float* out = a.slab + ((long long)jr * 16) * a.Cin * a.Cout;
   const int co = cob * 64 + wn * 32 + li;
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi)
@@ -922,7 +932,16 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   return 0;
 }
 
-extern "C" long long cy_wino_wgrad_ws_floats(int B, int Cin, int Cout) { return (long long)B * 16 * Cin * Cout; }
+// ranges of tile groups (= blocks and slabs per (ci, co) tile): about one block per CU whatever the batch and map size
+static int wino_wgrad_ranges(int Cin, int Cout) {
+  const int tiles = (Cin / 64) * (Cout / 64);
+  int r = (256 + tiles - 1) / tiles;
+  return r < 1 ? 1 : r;
+}
+extern "C" long long cy_wino_wgrad_ws_floats(int B, int Cin, int Cout) {
+  (void)B;
+  return (long long)wino_wgrad_ranges(Cin, Cout) * 16 * Cin * Cout;
+}
 
 extern "C" int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int W, int Cin,
                                          int Cout, void* stream) {
@@ -934,7 +953,11 @@ extern "C" int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float*
   WinoWgradArgs a;
   a.X = X; a.dZ = dZ; a.slab = ws; a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.gh = (H + 3) / 4; a.gw = (W + 7) / 8;
-  const long long blocks = (long long)B * (Cin / 64) * (Cout / 64);
+  a.nrange = wino_wgrad_ranges(Cin, Cout);
+  const long long gtot = (long long)B * a.gh * a.gw;
+  if (a.nrange > gtot / 8) a.nrange = gtot >= 8 ? (int)(gtot / 8) : 1;   // at least 8 chunks per block (workspace: upper bound)
+  CY_REQUIRE(gtot < (1ll << 31), "cy_conv3x3_winograd_wgrad: too many tile groups");
+  const long long blocks = (long long)a.nrange * (Cin / 64) * (Cout / 64);
   const size_t lds = (size_t)(4 * VU_BUF + RAWW_BUF) * 4;
   int rc = cy_allow_lds(wino_wgrad_kernel, lds);
   if (rc) return rc;
@@ -942,7 +965,7 @@ extern "C" int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float*
   wino_wgrad_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd_wgrad");
   const long long n = (long long)Cin * Cout;
-  wino_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B, Cin, Cout);
+  wino_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, a.nrange, Cin, Cout);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd_wgrad(finish)");
   return 0;
 }

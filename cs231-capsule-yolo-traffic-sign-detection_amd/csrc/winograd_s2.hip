@@ -823,7 +823,7 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   a.Ho = H / 2; a.Wo = W / 2;
   a.gh = (a.Ho + 3) / 4; a.gw = (a.Wo + 7) / 8;
   a.nsplit = wino2_wgrad_splits(B, Cin, Cout);
-  if (a.nsplit > a.gh * a.gw) a.nsplit = 1;             // (the workspace is sized for the larger count)
+  while (a.nsplit > a.gh * a.gw) a.nsplit >>= 1;         // (the workspace is sized for the larger count)
   const long long blocks = (long long)B * a.nsplit * (4 * Cin / WQ) * (Cout / 64);
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_wgrad: grid too large");
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + RAWG_BUF) * 4;

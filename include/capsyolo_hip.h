@@ -93,8 +93,9 @@ int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* b
                         int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through Winograd F(3x3,2x2): dW[Cout][Cin][3][3] from X[B][H][W][Cin] and
  * dZ[B][H][W][Cout] (replaces the weight-gradient half of nn.Conv2d backward, models.py:132-223 conv_2 class of
- * layers).  Cin % 64 == 0 and Cout % 64 == 0.  ws: cy_wino_wgrad_ws_floats(B, Cin, Cout) floats (per-image
- * Winograd-domain partial sums, reduced in a fixed order: the result is deterministic). */
+ * layers).  Cin % 64 == 0 and Cout % 64 == 0.  ws: cy_wino_wgrad_ws_floats(B, Cin, Cout) floats (Winograd-domain
+ * partial sums, one slab per contiguous range of tile groups -- the batch's B * ceil(H/4) * ceil(W/8) groups are dealt to
+ * about one block per CU whatever the batch and map size -- reduced in a fixed order: the result is deterministic). */
 long long cy_wino_wgrad_ws_floats(int B, int Cin, int Cout);
 int cy_conv3x3_winograd_wgrad(const float* X, const float* dZ, float* dW, float* ws,
                               int B, int H, int W, int Cin, int Cout, void* stream);
