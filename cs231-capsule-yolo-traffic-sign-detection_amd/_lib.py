@@ -60,6 +60,8 @@ _SIGS = {
     'cy_wino2_pack_weights': [_P, _P, _I, _I, _P],
     'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_conv4x4s2_winograd_wgrad': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    'cy_wino2_pack_dgrad_weights': [_P, _P, _I, _I, _P],
+    'cy_conv4x4s2_winograd_dgrad': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     'cy_bn_finalize': [_P, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P],
     'cy_bn_eval_scale_shift': [_P, _P, _P, _P, _F, _P, _P, _I, _P],
     'cy_affine_act': [_P, _P, _P, _P, _F, _L, _I, _P],
@@ -98,6 +100,7 @@ _RET = {
     'cy_conv_packed_floats': (_L, [_I, _I]),
     'cy_wino_packed_floats': (_L, [_I, _I]),
     'cy_wino2_packed_floats': (_L, [_I, _I]),
+    'cy_wino2_dgrad_packed_floats': (_L, [_I, _I]),
     'cy_wino2_wgrad_ws_floats': (_L, [_I, _I, _I]),
     'cy_wino_wgrad_ws_floats': (_L, [_I, _I, _I]),
     'cy_conv_wgrad_ws_floats': (_L, [C.POINTER(ConvWgrad)]),

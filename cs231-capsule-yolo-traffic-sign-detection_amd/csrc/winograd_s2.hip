@@ -33,6 +33,11 @@ struct Wino2Args {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
   const float* in_scale; const float* in_shift; float in_slope;   // optional: the input is lrelu(X * scale[c] + shift[c])
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
+  // input-gradient mode only: Y = dX [B][Hx][Wx][Cx] of the layer, scattered from the (Ho x Wo = Hx/2+1 x Wx/2+1) grid of
+  // the space-to-depth view; optional BatchNorm-backward sums of the producer block (cy_conv_gemm_t.bn_*)
+  int Hx, Wx, Cx;
+  const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+  double* bn_red; float bn_slope;
 };
 
 // 18 accumulator tiles = 288 registers, the AGPR file has 256: left to itself the compiler shuttles accumulators
@@ -106,6 +111,12 @@ constexpr int s2_younger(int xi) {
   return n > 14 ? 14 : n;
 }
 
+// MODE 0: forward (X = layer input, sampled with stride 2 per (py, px) class).
+// MODE 1: input gradient.  dX'(Y, X, q) = sum_{a',b'} D(Y + a', X + b', co) h(q, co, a', b') with D(Y, X) = dY(Y - 1, X - 1)
+// (zero outside) and h(q, co, a', b') = g'(co, q, 1 - a', 1 - b'): the same 2x2 "valid" convolution, over the plain NHWC
+// tensor dY shifted by one pixel, with K = Cout of the layer (chunks of 8 output channels) and N = 4 Cin; the epilogue
+// scatters element (Y, X, q = (py, px, c)) to dX(2Y - 1 + py, 2X - 1 + px, c).
+template <int MODE>
 __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][V2_BUF]
@@ -133,13 +144,15 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   const int b = rest / a.tbh;
   const int Y0 = tby * (2 * TR2), X0 = tbx * (2 * TC2);      // first output row / column = first X' row / column
   const int cpp = a.Cin / 8;                // chunks per (py, px)
-  const int nchunk = 4 * cpp;
+  const int nchunk = MODE == 0 ? 4 * cpp : cpp;
+  constexpr int SXY = MODE == 0 ? 2 : 1;    // input pixels per grid step
 
   // ---- patch loader: item = t + 256 q -> 16 pixels x 2 k-quads per 32 items (conflict-free b128 LDS stores, both
   // 16-byte halves of a pixel's 32 bytes in one wave-load)
   int roff[NRAWQ]; int iy00[NRAWQ], ix00[NRAWQ]; bool rvalid[NRAWQ];
   unsigned gvoff[NRAWQ];                    // byte offset of (py, px) = (0, 0), channel 0 from the image base (fast path)
-  const bool blk_fast = Y0 >= 1 && X0 >= 1 && 2 * (Y0 + PR2 - 1) + 1 <= a.H - 1 && 2 * (X0 + PC2 - 1) + 1 <= a.W - 1;   // uniform
+  const bool blk_fast = Y0 >= 1 && X0 >= 1 && SXY * (Y0 + PR2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.H - 1 &&
+                        SXY * (X0 + PC2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.W - 1;   // uniform
   const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);
 #pragma unroll
   for (int q = 0; q < NRAWQ; ++q) {
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
     rvalid[q] = pix < NPIX2;
     const int pr = pix / PC2, pc = pix - pr * PC2;
-    iy00[q] = 2 * (Y0 + pr) - 1; ix00[q] = 2 * (X0 + pc) - 1;
+    iy00[q] = SXY * (Y0 + pr) - 1; ix00[q] = SXY * (X0 + pc) - 1;
     roff[q] = rvalid[q] ? (kq * RAWP2 + pix) * 4 : -1;
     gvoff[q] = (blk_fast && rvalid[q]) ? (unsigned)(((iy00[q] * a.W + ix00[q]) * a.Cin + kq * 4) * 4) : 0u;
   }
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   f32x4 graw[NRAWQ], gu[NUQ];
   unsigned okm = 0;                         // slow path: bit q = graw[q] is inside the image
   auto chunk_pos = [&](int f, int& py, int& px, int& c0) {
+    if (MODE == 1) { py = 0; px = 0; c0 = f * 8; return; }
     const int ph = f / cpp;
     py = ph >> 1; px = ph & 1; c0 = (f - ph * cpp) * 8;
   };
@@ -324,6 +338,88 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     __syncthreads();                        // the only barrier of the chunk
   }
 
+  if (MODE == 1) {
+    // ---- input gradient: the same A^T M A; grid point (Yg, Xg) of q block nb = one (py, px) class and 64 channels of it
+    const int q0 = nb * 64;
+    const int ph = q0 / a.Cx, cb0 = q0 - ph * a.Cx, py = ph >> 1, px = ph & 1;
+    float* ow = smem + wave * 4096;
+    const int c4 = lane & 7;
+    const int cch = cb0 + wn * 32 + c4 * 4;               // first of this lane's 4 channels
+    const bool bnb = a.bn_red != nullptr;
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc, b1 = bsc, b2 = bsc;
+    if (bnb) {
+      bsc = *(const f32x4*)(a.bn_scale + cch); bsh = *(const f32x4*)(a.bn_shift + cch);
+      bmu = *(const f32x4*)(a.bn_mean + cch); bis = *(const f32x4*)(a.bn_invstd + cch);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        float m[9];
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) m[xi] = acc_elem(acc[xi][mi][r]);
+        m[8] = acc[8][mi][r];
+        float* op = ow + tloc * 128 + li;
+        op[0] = (m[0] + m[1]) + (m[3] + m[4]); op[32] = (m[1] + m[2]) + (m[4] + m[5]);
+        op[64] = (m[3] + m[4]) + (m[6] + m[7]); op[96] = (m[4] + m[5]) + (m[7] + m[8]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      long long offs[16];
+      f32x4 zq_[16];
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {                     // addresses, and all bn_z loads before the first use
+        const int p = it * 8 + (lane >> 3);
+        const int tl = wm * 64 + mi * 32 + (p >> 2), ab = p & 3;
+        const int Yg = Y0 + 2 * (tl >> 4) + (ab >> 1), Xg = X0 + 2 * (tl & 15) + (ab & 1);
+        const int iy = 2 * Yg - 1 + py, ix = 2 * Xg - 1 + px;
+        const bool ok = Yg < a.Ho && Xg < a.Wo && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
+        offs[it] = ok ? (((long long)b * a.Hx + iy) * a.Wx + ix) * a.Cx + cch : -1;
+        if (bnb) zq_[it] = *(const f32x4*)(a.bn_z + (ok ? offs[it] : 0));
+      }
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int p = it * 8 + (lane >> 3);
+        const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
+        if (offs[it] >= 0) {
+          *(f32x4*)(a.Y + offs[it]) = v;
+          if (bnb) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const float y = zq_[it][k] * bsc[k] + bsh[k];
+              const float d = y > 0.f ? v[k] : v[k] * a.bn_slope;
+              b1[k] += d;
+              b2[k] += d * ((zq_[it][k] - bmu[k]) * bis[k]);
+            }
+          }
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (bnb) {                               // lanes with the same channel quad, then the two waves with the same wn
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int msk = 8; msk < 64; msk <<= 1) { b1[k] += __shfl_xor(b1[k], msk, 64); b2[k] += __shfl_xor(b2[k], msk, 64); }
+      __syncthreads();
+      float* bred = smem;                    // [2 wm][64][2]
+      if (lane < 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int col = wn * 32 + c4 * 4 + k;
+          bred[(wm * 64 + col) * 2 + 0] = b1[k];
+          bred[(wm * 64 + col) * 2 + 1] = b2[k];
+        }
+      }
+      __syncthreads();
+      if (t < 64) {
+        double* rd = a.bn_red + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.Cx * 2;
+        atomicAdd(rd + 2 * (cb0 + t), (double)bred[t * 2] + (double)bred[(64 + t) * 2]);
+        atomicAdd(rd + 2 * (cb0 + t) + 1, (double)bred[t * 2 + 1] + (double)bred[(64 + t) * 2 + 1]);
+      }
+    }
+    return;
+  }
   // ---- output transform (lane-local) Y = A^T M A, A^T = [[1,1,0],[0,1,1]], one 32-tile half of the wave at a time
   // through the wave's private 16 KiB of LDS (16-byte global stores), BatchNorm statistics from the same registers
   const int co = nb * 64 + wn * 32 + li;
@@ -753,6 +849,34 @@ __global__ void wino2_wgrad_finish_kernel(const float* __restrict__ slab, float*
   o[(2 + py) * 4 + 2 + px] = (m[4] + m[5]) + (m[7] + m[8]);
 }
 
+// input-gradient weights: U[chunk f = co/8][xi = i*3+j][kq][q (Np = 4 Cin)][e] = (G h G^T)[i][j] for co = f*8 + kq*4 + e,
+// h[a'][b'] = W[co][c][2(1-a')+py][2(1-b')+px] with q = (py*2+px) * Cin + c
+__global__ void wino2_pack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout, int Cin, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int Np = 4 * Cin;
+  const int e = (int)(idx & 3);
+  long long r = idx >> 2;
+  const int q = (int)(r % Np); r /= Np;
+  const int kq = (int)(r & 1); r >>= 1;
+  const int xi = (int)(r % 9); r /= 9;
+  const int co = (int)r * 8 + kq * 4 + e;
+  const int ph = q / Cin, c = q - ph * Cin, py = ph >> 1, px = ph & 1;
+  float u = 0.f;
+  if (co < Cout) {
+    float h[2][2];
+#pragma unroll
+    for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+      for (int bb = 0; bb < 2; ++bb) h[aa][bb] = W[(((long long)co * Cin + c) * 4 + (2 * (1 - aa) + py)) * 4 + (2 * (1 - bb) + px)];
+    const int i = xi / 3, j = xi % 3;
+    const float r0 = i == 0 ? h[0][0] : i == 1 ? h[0][0] + h[1][0] : h[1][0];
+    const float r1 = i == 0 ? h[0][1] : i == 1 ? h[0][1] + h[1][1] : h[1][1];
+    u = j == 0 ? r0 : j == 1 ? r0 + r1 : r1;
+  }
+  U[idx] = u;
+}
+
 }  // namespace
 
 extern "C" long long cy_wino2_packed_floats(int Cin, int N) {
@@ -789,9 +913,10 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd: grid too large");
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF + (in_scale ? 2 * Cin : 0)) * 4;
   CY_REQUIRE(lds <= 160 * 1024, "cy_conv4x4s2_winograd: Cin=%d too large for the fused input affine", Cin);
-  int rc = cy_allow_lds(wino2_conv_kernel, lds);
+  a.Hx = a.Wx = a.Cx = 0; a.bn_z = a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr; a.bn_red = nullptr; a.bn_slope = 0.f;
+  int rc = cy_allow_lds(wino2_conv_kernel<0>, lds);
   if (rc) return rc;
-  wino2_conv_kernel<<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  wino2_conv_kernel<0><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd");
   return 0;
 }
@@ -835,5 +960,45 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   const long long n = (long long)4 * Cin * Cout;
   wino2_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B * a.nsplit, Cin, Cout);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad(finish)");
+  return 0;
+}
+
+/* ---- input gradient of the 4x4 / stride 2 / pad 1 layers */
+extern "C" long long cy_wino2_dgrad_packed_floats(int Cin, int Cout) { return (long long)(Cout / 8) * 18 * (4 * Cin) * 4; }
+
+extern "C" int cy_wino2_pack_dgrad_weights(const float* W, float* U, int Cout, int Cin, void* stream) {
+  CY_REQUIRE(W && U && Cout > 0 && Cin > 0 && Cout % 8 == 0 && Cin % 16 == 0, "cy_wino2_pack_dgrad_weights: bad arguments");
+  const long long total = cy_wino2_dgrad_packed_floats(Cin, Cout);
+  wino2_pack_dgrad_kernel<<<(unsigned)cy_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(W, U, Cout, Cin, total);
+  CY_LAUNCH_CHECK("cy_wino2_pack_dgrad_weights");
+  return 0;
+}
+
+extern "C" int cy_conv4x4s2_winograd_dgrad(const float* dZ, const float* U, float* dX, const float* bn_z, const float* bn_scale,
+                                           const float* bn_shift, const float* bn_mean, const float* bn_invstd, float bn_slope,
+                                           double* bn_red, int B, int H, int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE(dZ && U && dX && B > 0 && H > 0 && W > 0, "cy_conv4x4s2_winograd_dgrad: bad arguments");
+  CY_REQUIRE(Cin % 64 == 0 && Cout % 8 == 0, "cy_conv4x4s2_winograd_dgrad: Cin=%d must be a multiple of 64, Cout=%d of 8", Cin, Cout);
+  CY_REQUIRE(H % 2 == 0 && W % 2 == 0, "cy_conv4x4s2_winograd_dgrad: H=%d, W=%d must be even", H, W);
+  CY_REQUIRE((((uintptr_t)dZ | (uintptr_t)U | (uintptr_t)dX | (uintptr_t)bn_z) & 15) == 0, "cy_conv4x4s2_winograd_dgrad: operands must be 16-byte aligned");
+  CY_REQUIRE(bn_red == nullptr || (bn_z && bn_scale && bn_shift && bn_mean && bn_invstd), "cy_conv4x4s2_winograd_dgrad: bn_red needs bn_z / scale / shift / mean / invstd");
+  CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd_dgrad: image too large for 32-bit offsets");
+  Wino2Args a;
+  a.X = dZ; a.U = U; a.Y = dX; a.bias = nullptr; a.stats = nullptr;
+  a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
+  a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout;          // the kernel's "input" is dY [B][H/2][W/2][Cout]
+  a.Cout = 4 * Cin; a.Np = 4 * Cin;
+  a.Ho = H / 2 + 1; a.Wo = W / 2 + 1;                       // grid of the space-to-depth view
+  a.tbh = (a.Ho + 2 * TR2 - 1) / (2 * TR2); a.tbw = (a.Wo + 2 * TC2 - 1) / (2 * TC2);
+  a.Hx = H; a.Wx = W; a.Cx = Cin;
+  a.bn_z = bn_z; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+  a.bn_red = bn_red; a.bn_slope = bn_slope;
+  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / 64);
+  CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_dgrad: grid too large");
+  const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF) * 4;
+  int rc = cy_allow_lds(wino2_conv_kernel<1>, lds);
+  if (rc) return rc;
+  wino2_conv_kernel<1><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_dgrad");
   return 0;
 }

@@ -79,6 +79,7 @@ def _x_geometry(x, nchw):
 
 
 STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
+USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short reductions; kept switchable)
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 
@@ -187,6 +188,18 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv', bn_fuse=None):
         return _winograd(dz, weight, None, None, True, tag)
     st = _stream()
     dx = _empty((B, Hi, Wi, Cin), dz)
+    if (USE_WINOGRAD and USE_WINOGRAD_S2 and USE_WINOGRAD_S2_DGRAD and k == 4 and stride == 2 and pad == 1 and Cin % 64 == 0
+            and Cout % 8 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and dz.is_contiguous()):
+        u = _empty((query('cy_wino2_dgrad_packed_floats', Cin, Cout),), dz)
+        call('cy_wino2_pack_dgrad_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
+        bz = bsc = bsh = bmu = bis = bred = None
+        bsl = 0.0
+        if bn_fuse is not None:
+            bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
+        with timer.range('conv_wino2_dgrad/' + tag):
+            call('cy_conv4x4s2_winograd_dgrad', _ptr(dz), _ptr(u), _ptr(dx), _ptr(bz), _ptr(bsc), _ptr(bsh), _ptr(bmu),
+                 _ptr(bis), float(bsl), _ptr(bred), B, Hi, Wi, Cin, Cout, st)
+        return dx
     wp = _empty((query('cy_conv_packed_floats', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dz)
     for c in dgrad_classes(Hi, Wi, k, stride, pad):
         call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, c['TH'], c['TW'], c['kh0'], c['kw0'],

@@ -120,6 +120,15 @@ int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, float* dW, floa
                                 const float* in_scale, const float* in_shift, float in_slope,
                                 int B, int H, int W, int Cin, int Cout, void* stream);
 
+/* Input gradient of the same layers through F(2x2,2x2): dX[B][H][W][Cin] from dZ[B][H/2][W/2][Cout]
+ * (U = cy_wino2_pack_dgrad_weights(W[Cout][Cin][4][4])).  Cin % 64 == 0, Cout % 8 == 0, H and W even.  bn_* as in
+ * cy_conv_gemm_t (optional BatchNorm-backward sums of the producer block; bn_red[CY_STATS_COPIES][Cin][2]). */
+long long cy_wino2_dgrad_packed_floats(int Cin, int Cout);
+int cy_wino2_pack_dgrad_weights(const float* W, float* U, int Cout, int Cin, void* stream);
+int cy_conv4x4s2_winograd_dgrad(const float* dZ, const float* U, float* dX, const float* bn_z, const float* bn_scale,
+                                const float* bn_shift, const float* bn_mean, const float* bn_invstd, float bn_slope,
+                                double* bn_red, int B, int H, int W, int Cin, int Cout, void* stream);
+
 /* per-channel sum over pixels: out[N] = sum_p dZ[p][n]  (bias gradient of convs without BatchNorm) */
 int cy_channel_sum(const float* dZ, float* out, long long P, int N, void* stream);
 

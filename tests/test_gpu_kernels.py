@@ -248,6 +248,36 @@ def test_conv_dgrad_epilogue_bn_backward_sums(case):
     close(red.sum(0), ref, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize('case', [(2, 64, 32, 64), (1, 64, 10, 8), (3, 128, 70, 40), (2, 256, 36, 64), (5, 64, 6, 16)])
+def test_conv4x4s2_winograd_dgrad_matches_direct_and_fp64(case):
+    """Winograd F(2x2,2x2) input gradient of the 4x4 / stride 2 / pad 1 layers (scatter through the space-to-depth view,
+    image borders, grid overhang) against torch fp64 and the direct per-parity-class kernel."""
+    from capsyolo_amd import ops
+    B, Cin, H, Cout = case
+    x = rnd((B, Cin, H, H), 121)
+    w = rnd((Cout, Cin, 4, 4), 122, (1.0 / (Cin * 16)) ** 0.5)
+    xd = x.double().requires_grad_(True)
+    zr = F.conv2d(xd, w.double(), None, stride=2, padding=1)
+    gz = rnd(tuple(zr.shape), 124)
+    zr.backward(gz.double())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        dx = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), 4, 2, 1, 'dg')
+    finally:
+        ops.timer.enabled = False
+    torch.cuda.synchronize()
+    assert 'conv_wino2_dgrad/dg' in ops.timer.summary()
+    close(dx.permute(0, 3, 1, 2), xd.grad, 2e-5, 2e-5)
+    try:
+        ops.USE_WINOGRAD_S2_DGRAD = False
+        dx2 = ops.conv_dgrad(gzd, w.to(dev()), (B, H, H, Cin), 4, 2, 1)
+    finally:
+        ops.USE_WINOGRAD_S2_DGRAD = True
+    close(dx, dx2, 4e-5, 4e-5)
+
+
 def test_conv_relu_epilogue_and_stats():
     from capsyolo_amd import ops
     x = rnd((2, 64, 9, 9), 5)
