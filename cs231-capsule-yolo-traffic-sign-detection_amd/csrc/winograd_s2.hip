@@ -14,6 +14,11 @@
 // tiles x 32 channels x 9 positions = 18 accumulator tiles (288 registers); per chunk 72 MFMAs per wave, every other
 // piece of work (U / patch global loads, LDS stores, the input transform on channel pairs with v_pk_add_f32) in one
 // of the 72 slots between them.  9 global loads per 72 MFMAs (the 3x3 kernel has 11 per 64).
+#include <type_traits>
+#ifndef W2_SKIP
+#define W2_SKIP 0
+#endif
+#define W2_SKIPPED(k) ((((W2_SKIP) & 1) && ((k) == 4 || (k) == 5)) || (((W2_SKIP) & 2) && ((k) == 1 || (k) == 7)) || (((W2_SKIP) & 4) && ((k) == 2 || (k) == 3)))
 #include "common.h"
 
 namespace {
@@ -33,6 +38,7 @@ struct Wino2Args {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
   const float* in_scale; const float* in_shift; float in_slope;   // optional: the input is lrelu(X * scale[c] + shift[c])
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
+  int ntiles;                               // B * tbh * tbw * Np/64 output tiles, walked by a persistent grid
   // input-gradient mode only: Y = dX [B][Hx][Wx][Cx] of the layer, scattered from the (Ho x Wo = Hx/2+1 x Wx/2+1) grid of
   // the space-to-depth view; optional BatchNorm-backward sums of the producer block (cy_conv_gemm_t.bn_*)
   int Hx, Wx, Cx;
@@ -64,7 +70,12 @@ __device__ __forceinline__ f32x4 affine_lrelu4(f32x4 v, f32x4 sc, f32x4 sh, floa
   f32x2 lo2, hi2;
   asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo2) : "v"(lo), "v"(sl));
   asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi2) : "v"(hi), "v"(sl));
-  return f32x4{fmaxf(lo[0], lo2[0]), fmaxf(lo[1], lo2[1]), fmaxf(hi[0], hi2[0]), fmaxf(hi[1], hi2[1])};
+  f32x4 r;                                  // plain v_max_f32: fmaxf() would first canonicalise both operands (3 ops)
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[0]) : "v"(lo[0]), "v"(lo2[0]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[1]) : "v"(lo[1]), "v"(lo2[1]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[2]) : "v"(hi[0]), "v"(hi2[0]));
+  asm("v_max_f32 %0, %1, %2" : "=v"(r[3]) : "v"(hi[1]), "v"(hi2[1]));
+  return r;
 }
 __device__ __forceinline__ float acc_elem(float a_elem) {   // one accumulator element, read where the statement stands
   float x;
@@ -75,21 +86,28 @@ __device__ __forceinline__ float acc_elem(float a_elem) {   // one accumulator e
 // ---- compile-time schedule of one chunk: 72 slots; slot s issues the MFMA of position s / 8, row tile s & 1,
 // k-step (s >> 1) & 3 (consecutive MFMAs alternate between the position's two accumulators).  Position xi + 1's three
 // fragments (A0, A1, B) are fetched in the first three slots of position xi.
+// Loads retire in order: the U loads of a chunk are issued BEFORE its patch loads because S_U (slots 3, 4 of the next
+// chunk) consumes them first -- with the two interleaved, S_U waited for the youngest load and so for every patch load
+// (HBM latency) of the chunk.  Each patch load directly follows the LDS store that frees its registers.
 constexpr int S2_SU[2] = {3, 4};
-constexpr int S2_SRAW[5] = {5, 6, 7, 11, 12};
-constexpr int S2_GRAW[5] = {13, 15, 20, 22, 27};
-constexpr int S2_GU[5] = {14, 19, 21, 23, 28};
+constexpr int S2_GU[5] = {5, 6, 7, 11, 12};
+constexpr int S2_SRAW[5] = {13, 15, 20, 22, 27};
+constexpr int S2_GRAW[5] = {14, 19, 21, 23, 28};
 constexpr int S2_TRD[9] = {29, 30, 31, 35, 36, 37, 38, 39, 43};
 constexpr int S2_TV[6] = {44, 45, 46, 47, 51, 52};
+// cursor bookkeeping for the next chunk (scalar work, hidden under the MFMAs instead of standing between two chunks)
+constexpr int S2_ADV_RAW = 53, S2_ADV_U = 54;
 constexpr int s2_find(const int* list, int n, int s) {
   for (int i = 0; i < n; ++i) if (list[i] == s) return i;
   return -1;
 }
 // kinds: 1 S_U (LDS writes of U(c+1): 3 + 2)  7 S_raw (one float4 of patch c+2)  2 G_raw (one load of patch c+3)
 //        3 G_U (one load of U c+2)  4 T_rd (two float2 of patch c+1)  5 T_v (one row of V for one of the two items)
+//        8 / 9 advance the patch / U cursor to the next chunk (after this chunk's loads were issued)
 constexpr int s2_kind(int s) {
   return s2_find(S2_SU, 2, s) >= 0 ? 1 : s2_find(S2_SRAW, 5, s) >= 0 ? 7 : s2_find(S2_GRAW, 5, s) >= 0 ? 2
-       : s2_find(S2_GU, 5, s) >= 0 ? 3 : s2_find(S2_TRD, 9, s) >= 0 ? 4 : s2_find(S2_TV, 6, s) >= 0 ? 5 : 0;
+       : s2_find(S2_GU, 5, s) >= 0 ? 3 : s2_find(S2_TRD, 9, s) >= 0 ? 4 : s2_find(S2_TV, 6, s) >= 0 ? 5
+       : s == S2_ADV_RAW ? 8 : s == S2_ADV_U ? 9 : 0;
 }
 constexpr int s2_idx(int s) {
   const int k = s2_kind(s);
@@ -99,8 +117,8 @@ constexpr int s2_idx(int s) {
 // LOWER bound of the LDS instructions a slot's side work issues (two float2 reads may merge into one ds_read2_b64;
 // exec-masked stores may be skipped by a whole wave)
 constexpr int s2_side_lds(int s) {
-  const int k = s2_kind(s), i = s2_idx(s);
-  return k == 1 ? (i == 0 ? 3 : 1) : k == 7 ? (i < 4 ? 1 : 0) : k == 4 ? 1 : k == 5 ? 3 : 0;
+  const int k = W2_SKIPPED(s2_kind(s)) ? 0 : s2_kind(s), i = s2_idx(s);
+  return k == 1 ? (i == 0 ? 3 : 2) : k == 7 ? 1 : k == 4 ? 1 : k == 5 ? 3 : 0;
 }
 constexpr int s2_frag_lds(int s) { return ((s & 7) < 3 && s + 8 < 72) ? 1 : 0; }
 // LDS operations younger than position xi's last fragment (B) when its first MFMA issues
@@ -116,7 +134,8 @@ constexpr int s2_younger(int xi) {
 // (zero outside) and h(q, co, a', b') = g'(co, q, 1 - a', 1 - b'): the same 2x2 "valid" convolution, over the plain NHWC
 // tensor dY shifted by one pixel, with K = Cout of the layer (chunks of 8 output channels) and N = 4 Cin; the epilogue
 // scatters element (Y, X, q = (py, px, c)) to dX(2Y - 1 + py, 2X - 1 + px, c).
-template <int MODE>
+// AFFINE: the input is lrelu(X * in_scale[c] + in_shift[c]) (forward only), applied on the way from registers to LDS.
+template <int MODE, bool AFFINE>
 __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][V2_BUF]
@@ -128,93 +147,134 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave & 1, wn = wave >> 1;
   const int li = lane & 31, lh = lane >> 5;
-  const bool affine = a.in_scale != nullptr;      // uniform
+  constexpr bool affine = AFFINE;
   if (affine) {
     for (int i = t; i < a.Cin; i += 256) { Aff[i] = a.in_scale[i]; Aff[a.Cin + i] = a.in_shift[i]; }
     __syncthreads();
   }
 
-  unsigned vid = blockIdx.x;                // XCD-aware ids: the Np/64 blocks of one patch share an L2 (winograd.hip)
+  // Persistent grid, one block per CU, as in winograd.hip: block j walks the tiles vid(j), vid(j) + G, ... as ONE
+  // continuous stream of chunks (the input gradient has only Cout/8 chunks per tile: without this every tile pays a
+  // prologue and a block launch).  XCD-aware ids: the Np/64 tiles of one patch are in flight together on one L2.
+  unsigned vid = blockIdx.x;
   if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int nblk = a.Np / 64;
-  const int nb = vid % nblk;
-  int rest = vid / nblk;
-  const int tbx = rest % a.tbw; rest /= a.tbw;
-  const int tby = rest % a.tbh;
-  const int b = rest / a.tbh;
-  const int Y0 = tby * (2 * TR2), X0 = tbx * (2 * TC2);      // first output row / column = first X' row / column
+  const int ntile_mine = (a.ntiles - (int)vid + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= ntiles)
   const int cpp = a.Cin / 8;                // chunks per (py, px)
   const int nchunk = MODE == 0 ? 4 * cpp : cpp;
   constexpr int SXY = MODE == 0 ? 2 : 1;    // input pixels per grid step
+  struct TilePos { int nb, b, Y0, X0; };    // Y0 / X0 = first output row / column = first X' row / column
+  auto tile_pos = [&](int k) {              // k-th tile of this block (uniform)
+    const int id = (int)vid + k * (int)gridDim.x;
+    TilePos p;
+    p.nb = id % nblk;
+    int rest = id / nblk;
+    const int tbx = rest % a.tbw; rest /= a.tbw;
+    const int tby = rest % a.tbh;
+    p.b = rest / a.tbh; p.Y0 = tby * (2 * TR2); p.X0 = tbx * (2 * TC2);
+    return p;
+  };
 
   // ---- patch loader: item = t + 256 q -> 16 pixels x 2 k-quads per 32 items (conflict-free b128 LDS stores, both
-  // 16-byte halves of a pixel's 32 bytes in one wave-load)
-  int roff[NRAWQ]; int iy00[NRAWQ], ix00[NRAWQ]; bool rvalid[NRAWQ];
-  unsigned gvoff[NRAWQ];                    // byte offset of (py, px) = (0, 0), channel 0 from the image base (fast path)
-  const bool blk_fast = Y0 >= 1 && X0 >= 1 && SXY * (Y0 + PR2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.H - 1 &&
-                        SXY * (X0 + PC2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.W - 1;   // uniform
-  const char* ximg = (const char*)(a.X + (long long)b * a.H * a.W * a.Cin);
-#pragma unroll
-  for (int q = 0; q < NRAWQ; ++q) {
-    const int item = t + 256 * q;
-    const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
-    rvalid[q] = pix < NPIX2;
-    const int pr = pix / PC2, pc = pix - pr * PC2;
-    iy00[q] = SXY * (Y0 + pr) - 1; ix00[q] = SXY * (X0 + pc) - 1;
-    roff[q] = rvalid[q] ? (kq * RAWP2 + pix) * 4 : -1;
-    gvoff[q] = (blk_fast && rvalid[q]) ? (unsigned)(((iy00[q] * a.W + ix00[q]) * a.Cin + kq * 4) * 4) : 0u;
-  }
+  // 16-byte halves of a pixel's 32 bytes in one wave-load).  pix(q) = pix0 + 128 q, LDS offset roff0 + 512 q; only the
+  // last round (q = 4) is partial.  The tile-dependent values belong to the tile the patch stream is in (set_raw_tile).
   const int kq_of_thread = (t >> 4) & 1;    // k-quad of every item of this thread (256 q keeps bit 4)
-  // ---- U loader: 18 segments (xi * 2 + kq) of 64 channels x float4 per chunk
-  const long long uchunk = (long long)18 * a.Np * 4;           // floats per chunk
-  int useg_ok[NUQ]; unsigned uvoff[NUQ]; int uoff[NUQ];
+  const int pix0 = (t >> 5) * 16 + (t & 15);
+  const int roff0 = (kq_of_thread * RAWP2 + pix0) * 4;
+  const bool rlast_ok = pix0 + 128 * (NRAWQ - 1) < NPIX2;
+  const int roff4 = roff0 + 512 * (rlast_ok ? NRAWQ - 1 : NRAWQ - 2);   // no exec masks in the loop: duplicates instead
+  constexpr int NCLS = MODE == 0 ? 4 : 1;   // (py, px) classes of a tile's patches
+  unsigned gvoff[NRAWQ];                    // byte offset of class (0, 0), channel 0 from the image base (mod 2^32: the
+                                            // pixel of class (0, 0) may lie above / left of the image)
+  unsigned okbits = 0;                      // border tiles: bit 5 cls + q = item q of class cls is an image pixel
+  bool blk_fast = false;                    // uniform: the whole patch of the stream's tile lies inside the image
+  const char* ximg = nullptr;               // uniform
+  auto set_raw_tile = [&](int k) {
+    const TilePos p = tile_pos(k);
+    blk_fast = p.Y0 >= 1 && p.X0 >= 1 && SXY * (p.Y0 + PR2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.H - 1 &&
+               SXY * (p.X0 + PC2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.W - 1;
+    ximg = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin);
+    okbits = 0;
 #pragma unroll
-  for (int q = 0; q < NUQ; ++q) {
-    const int item = t + 256 * q;
-    const int seg = item >> 6, co = item & 63;
-    useg_ok[q] = seg < 18;
-    uvoff[q] = (unsigned)((((useg_ok[q] ? seg : 0) * a.Np) + nb * 64 + co) * 16);
-    uoff[q] = (useg_ok[q] ? seg : 0) * SLABU + co * 4;
-  }
+    for (int q = 0; q < NRAWQ; ++q) {
+      const int pix = pix0 + 128 * ((q < NRAWQ - 1 || rlast_ok) ? q : q - 1);   // past the patch: repeat the thread's item q - 1
+      const int pr = pix / PC2, pc = pix - pr * PC2;
+      const int iy = SXY * (p.Y0 + pr) - 1, ix = SXY * (p.X0 + pc) - 1;
+      constexpr bool item = true;
+      gvoff[q] = (unsigned)(((iy * a.W + ix) * a.Cin + kq_of_thread * 4) * 4);
+      if (!blk_fast) {
+#pragma unroll
+        for (int cls = 0; cls < NCLS; ++cls) {
+          const bool ok = item && (unsigned)(iy + (cls >> 1)) < (unsigned)a.H && (unsigned)(ix + (cls & 1)) < (unsigned)a.W;
+          okbits |= (unsigned)ok << (5 * cls + q);
+        }
+      }
+    }
+  };
+  // stream cursors (tile index within this block, chunk): advance by one chunk, stop at the very last chunk
+  auto advance = [&](int& k, int& c) {
+    if (c + 1 < nchunk) { ++c; return false; }
+    if (k + 1 < ntile_mine) { ++k; c = 0; return true; }
+    return false;
+  };
+  // ---- U loader: 18 segments (xi * 2 + kq) of 64 channels x float4 per chunk; item t + 256 q = segment (t >> 6) + 4 q,
+  // channel t & 63: one lane offset, uniform strides per q; only the last round (q = 4: segments 16, 17) is partial
+  const long long uchunk = (long long)18 * a.Np * 4;           // floats per chunk
+  const bool ulast_ok = t < 128;
+  const unsigned uvoff0 = (unsigned)((((t >> 6) * a.Np) + (t & 63)) * 16);   // bytes from the tile's first output channel
+  const long long useg4 = (long long)4 * a.Np * 16;                          // bytes per q
+  const unsigned uvoff4 = ulast_ok ? uvoff0 : uvoff0 - (unsigned)(2 * a.Np * 16);   // q = 4: segments 18, 19 do not exist
+  const int uoff0 = (t >> 6) * SLABU + (t & 63) * 4;                         // + q * 4 * SLABU
+  const int uoff4 = uoff0 + (NUQ - 1) * 4 * SLABU - (ulast_ok ? 0 : 2 * SLABU);   // waves 2, 3 repeat segments 16, 17
+  const char* ubase = nullptr;              // uniform: a.U + first output channel of the weight stream's tile
+  auto set_u_tile = [&](int k) { ubase = (const char*)(a.U + (long long)tile_pos(k).nb * 64 * 4); };
   // ---- transform items: channel pair tch = t & 1 of k-quad tkq, tile column (t >> 2) & 15, tile rows t >> 6 and + 4
   const int tch = t & 1, tkq = (t >> 1) & 1, ttx = (t >> 2) & 15, tty = t >> 6;
   const int tbase = (tkq * RAWP2 + (2 * tty) * PC2 + 2 * ttx) * 4 + 2 * tch;     // item 1: + 8 * PC2 * 4
   const int vdst = tkq * SLABV + (tty * TC2 + ttx) * 4 + 2 * tch;                // item 1: + 4 * TC2 * 4; + xi * 2 * SLABV
 
+  int km = 0, cm = 0, ku = 0, cu = 0, kr = 0, cr = 0;   // stream cursors (tile of this block, chunk): MFMAs, U loads, patch loads
   f32x4 graw[NRAWQ], gu[NUQ];
-  unsigned okm = 0;                         // slow path: bit q = graw[q] is inside the image
-  auto chunk_pos = [&](int f, int& py, int& px, int& c0) {
-    if (MODE == 1) { py = 0; px = 0; c0 = f * 8; return; }
-    const int ph = f / cpp;
-    py = ph >> 1; px = ph & 1; c0 = (f - ph * cpp) * 8;
+  // The slots of the MFMA stream must not branch (a uniform branch costs a one-wave-per-SIMD kernel ~40 cycles, ten of
+  // them 7 % of a chunk): every patch load is `uniform base + goff[q]`, every LDS store a select on one mask bit.  goff /
+  // okm_cur belong to the (tile, class) the patch cursor stands in and change only when it enters a new class or tile;
+  // pad items read the image's first bytes (a valid address) and are stored as exact zeros.
+  unsigned goff[NRAWQ];                     // byte offset of the cursor's class from the image base, 0 for pad items
+  unsigned okm_cur = 0;                     // bit q = item q of the cursor's (tile, class) is an image pixel
+  unsigned smask = 0;                       // the same for the patch held in graw (S_raw stores it next)
+  int rcc = 0, rcls = 0;                    // uniform: chunk within the class, class of the patch cursor
+  auto set_raw_class = [&](int cls) {
+    okm_cur = blk_fast ? 0x1fu : (okbits >> (5 * cls)) & 0x1fu;
+    const unsigned class_off = (unsigned)((((cls >> 1) * a.W + (cls & 1)) * a.Cin) * 4);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) goff[q] = (okm_cur >> q) & 1 ? gvoff[q] + class_off : 0u;
   };
-  auto Graw1 = [&](int q, int py, int px, int c0, f32x4& dst) {
-    if (blk_fast) {
-      dst = *(const f32x4*)(ximg + (size_t)(((py * a.W + px) * a.Cin + c0) * 4) + gvoff[q]);
-    } else {
-      const int iy = iy00[q] + py, ix = ix00[q] + px;
-      const bool ok = rvalid[q] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      dst = *(const f32x4*)(ximg + (ok ? (unsigned)(((iy * a.W + ix) * a.Cin + c0 + kq_of_thread * 4) * 4) : 0u));
-      okm = (okm & ~(1u << q)) | ((unsigned)ok << q);
+  auto advance_raw = [&]() {                // one chunk further; stops at the very last chunk of the block's stream
+    if (cr + 1 < nchunk) {
+      ++cr; ++rcc;
+      if (MODE == 0 && rcc == cpp) { rcc = 0; ++rcls; set_raw_class(rcls); }
+    } else if (kr + 1 < ntile_mine) {
+      ++kr; cr = 0; rcc = 0; rcls = 0;
+      set_raw_tile(kr);
+      set_raw_class(0);
     }
   };
+  auto Graw1 = [&](int q, const char* xc, f32x4& dst) { dst = *(const f32x4*)(xc + goff[q]); };
   f32x4 asc = {1.f, 1.f, 1.f, 1.f}, ash = {0.f, 0.f, 0.f, 0.f};     // scale / shift of the chunk that is being stored
-  auto set_affine = [&](int f) {            // f = chunk whose patch goes to LDS next
+  auto set_affine = [&](int c0) {           // c0 = first channel of the chunk whose patch goes to LDS next
     if (!affine) return;
-    const int c0 = (f % cpp) * 8 + kq_of_thread * 4;
-    asc = *(const f32x4*)(Aff + c0); ash = *(const f32x4*)(Aff + a.Cin + c0);
+    asc = *(const f32x4*)(Aff + c0 + kq_of_thread * 4); ash = *(const f32x4*)(Aff + a.Cin + c0 + kq_of_thread * 4);
   };
-  auto Sraw1 = [&](float* rb, int q, const f32x4& src) {
-    if (roff[q] < 0) return;
+  auto Sraw1 = [&](float* rb, int q, const f32x4& src, unsigned mask) {   // mask: bit q = src holds an image pixel
     const f32x4 v = affine ? affine_lrelu4(src, asc, ash, a.in_slope) : src;
-    if (blk_fast) *(f32x4*)(rb + roff[q]) = v;
-    else *(f32x4*)(rb + roff[q]) = (okm >> q) & 1 ? v : f32x4{0.f, 0.f, 0.f, 0.f};    // padding stays exactly 0
+    *(f32x4*)(rb + (q < NRAWQ - 1 ? roff0 + 512 * q : roff4)) = (mask >> q) & 1 ? v : f32x4{0.f, 0.f, 0.f, 0.f};   // padding: exact 0
   };
-  auto GU1 = [&](int q, int f, f32x4& dst) {
-    dst = *(const f32x4*)((const char*)a.U + (long long)f * uchunk * 4 + uvoff[q]);
+  auto GU1 = [&](int q, const char* uchunk_p, f32x4& dst) {
+    dst = *(const f32x4*)(uchunk_p + q * useg4 + (q < NUQ - 1 ? uvoff0 : uvoff4));
   };
+  auto uchunk_of = [&](int f) { return ubase + (long long)f * uchunk * 4; };   // uniform
   auto SU1 = [&](float* ub, int q, const f32x4& src) {
-    if (useg_ok[q]) *(f32x4*)(ub + uoff[q]) = src;
+    *(f32x4*)(ub + (q < NUQ - 1 ? uoff0 + q * 4 * SLABU : uoff4)) = src;
   };
   f32x2 xv[2][3][3];                        // the two 3x3 patches of this thread, two channels each
   auto Vrow = [&](float* vb, int it, int R) {   // row R of V = B^T d B of item `it`
@@ -242,6 +302,58 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
       for (int R = 0; R < 3; ++R) Vrow(vb, it, R);
   };
 
+  // ---- prologue (once per block).  State at the top of stream position f (tile km, chunk cm): V[f&1] / U[f&1] =
+  // position f, raw[(f+1)&1] = patch of position f+1, registers gu = U of position f+1, graw = patch of position f+2;
+  // the cursors (ku, cu) / (kr, cr) stand at the positions whose loads are issued during f: f+2 for U, f+3 for the patch.
+  int s_c0 = 0;                             // first channel of the patch held in graw
+  {
+    f32x4 graw1[NRAWQ];
+    set_raw_tile(0);
+    set_raw_class(0);
+    set_u_tile(0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, ximg, graw[q]);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) GU1(q, uchunk_of(0), gu[q]);
+    set_affine(0);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs, q, graw[q], okm_cur);
+    advance_raw();
+    const int c1 = rcc * 8;
+    const unsigned m1 = okm_cur;
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, ximg + rcc * 32, graw1[q]);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) SU1(Us, q, gu[q]);
+    if (advance(ku, cu)) set_u_tile(ku);
+#pragma unroll
+    for (int q = 0; q < NUQ; ++q) GU1(q, uchunk_of(cu), gu[q]);
+    __syncthreads();
+    Tall(0, 0);
+    set_affine(c1);
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs + RAW2_BUF, q, graw1[q], m1);
+    advance_raw();
+    s_c0 = rcc * 8; smask = okm_cur;
+#pragma unroll
+    for (int q = 0; q < NRAWQ; ++q) Graw1(q, ximg + rcc * 32, graw[q]);
+    __syncthreads();
+    advance_raw();
+    if (advance(ku, cu)) set_u_tile(ku);
+  }
+  const int fragA = lh * SLABV + (wm * 64 + li) * 4;     // + mi * 128
+  const int fragB = lh * SLABU + (wn * 32 + li) * 4;
+  int c_next = 0;                           // stream position f (only its parity is used)
+  const char* up_ = uchunk_of(cu);          // G_U(f+2); at the stream's end the cursors stop: the tail re-loads valid data
+  const char* xp_ = ximg + rcc * 32;        // G_raw(f+3)
+  set_affine(s_c0);                         // of the chunk S_raw stores next
+#ifdef W2_PROF
+  long long pf_loop = 0, pf_ep1 = 0, pf_ep2 = 0, pf_t0 = 0, pf_t1 = 0, pf_t2 = 0, pf_nfast = 0;
+#endif
+  for (km = 0; km < ntile_mine; ++km) {
+#ifdef W2_PROF
+  pf_t0 = clock64();
+#endif
   f32x16 acc[9][2];
 #pragma unroll
   for (int xi = 0; xi < 9; ++xi)
@@ -249,52 +361,21 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[xi][mi][r] = 0.f;
-
-  // ---- prologue.  State at the top of chunk c: V[c&1] / U[c&1] = chunk c, raw[(c+1)&1] = patch of chunk c+1,
-  // registers gu = U of chunk c+1, graw = patch of chunk c+2.
-  {
-    int py, px, c0;
-    f32x4 graw1[NRAWQ];
-    chunk_pos(0, py, px, c0);
-#pragma unroll
-    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw[q]);
-#pragma unroll
-    for (int q = 0; q < NUQ; ++q) GU1(q, 0, gu[q]);
-    set_affine(0);
-#pragma unroll
-    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs, q, graw[q]);
-    const int f1 = nchunk > 1 ? 1 : 0, f2 = nchunk > 2 ? 2 : nchunk - 1;
-    chunk_pos(f1, py, px, c0);
-#pragma unroll
-    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw1[q]);
-#pragma unroll
-    for (int q = 0; q < NUQ; ++q) SU1(Us, q, gu[q]);
-#pragma unroll
-    for (int q = 0; q < NUQ; ++q) GU1(q, f1, gu[q]);
-    __syncthreads();
-    Tall(0, 0);
-    set_affine(f1);
-#pragma unroll
-    for (int q = 0; q < NRAWQ; ++q) Sraw1(Rs + RAW2_BUF, q, graw1[q]);
-    chunk_pos(f2, py, px, c0);
-#pragma unroll
-    for (int q = 0; q < NRAWQ; ++q) Graw1(q, py, px, c0, graw[q]);
-    __syncthreads();
-  }
-  const int fragA = lh * SLABV + (wm * 64 + li) * 4;     // + mi * 128
-  const int fragB = lh * SLABU + (wn * 32 + li) * 4;
-  for (int c = 0; c < nchunk; ++c) {
+  for (cm = 0; cm < nchunk; ++cm, ++c_next) {
+    const int c = c_next;
     const float* vb_ = Vs + (c & 1) * V2_BUF + fragA;
     const float* ub_ = Us + (c & 1) * U2_BUF + fragB;
-    const float* rb_ = Rs + ((c + 1) & 1) * RAW2_BUF + tbase;       // T(c+1) reads ...
-    float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // ... and writes (harmless after the last chunk)
-    float* uw_ = Us + ((c + 1) & 1) * U2_BUF;                       // S_U(c+1)
-    float* rw_ = Rs + (c & 1) * RAW2_BUF;                           // S_raw(c+2) -> raw[(c+2)&1]
-    const int fu = (c + 2 < nchunk) ? c + 2 : nchunk - 1;           // G_U(c+2), clamped: the tail re-loads valid data
-    const int fr = (c + 3 < nchunk) ? c + 3 : nchunk - 1;           // G_raw(c+3)
-    int rpy, rpx, rc0;
-    chunk_pos(fr, rpy, rpx, rc0);
-    set_affine((c + 2 < nchunk) ? c + 2 : nchunk - 1);              // the chunk S_raw stores during this one
+    const float* rb_ = Rs + ((c + 1) & 1) * RAW2_BUF + tbase;       // T(f+1) reads ...
+    float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // ... and writes (harmless after the last position)
+    float* uw_ = Us + ((c + 1) & 1) * U2_BUF;                       // S_U(f+1)
+    float* rw_ = Rs + (c & 1) * RAW2_BUF;                           // S_raw(f+2) -> raw[(f+2)&1]
+#ifdef W2_PROF
+    unsigned long long st_[6];
+    st_[0] = __builtin_amdgcn_s_memtime();
+#define W2_STAMP(s_) if ((s_) == 24) st_[1] = __builtin_amdgcn_s_memtime(); if ((s_) == 48) st_[2] = __builtin_amdgcn_s_memtime();
+#else
+#define W2_STAMP(s_)
+#endif
     f32x4 fa_[2][2], fb_[2];                // fragment sets, indexed by position & 1
     fa_[0][0] = *(const f32x4*)(vb_);
     fa_[0][1] = *(const f32x4*)(vb_ + 128);
@@ -303,6 +384,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     {                                                                                               \
       constexpr int sidx = (SIDX);                                                                  \
       constexpr int xi = sidx >> 3, w_ = sidx & 7, mi = w_ & 1, e = w_ >> 1;                        \
+      W2_STAMP(sidx)                                                                                \
       if (w_ == 0) __builtin_amdgcn_s_waitcnt(0xC07F | (s2_younger(xi) << 8));                      \
       if (xi < 8) mfma_a(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                          \
       else mfma_v(acc[xi][mi], fa_[xi & 1][mi][e], fb_[xi & 1][e]);                                 \
@@ -312,22 +394,31 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
         if (w_ == 1) fa_[nx & 1][1] = *(const f32x4*)(vb_ + nx * 2 * SLABV + 128);                  \
         if (w_ == 2) fb_[nx & 1] = *(const f32x4*)(ub_ + nx * 2 * SLABU);                           \
       }                                                                                             \
-      constexpr int kind = s2_kind(sidx), k_ = s2_idx(sidx);                                        \
+      constexpr int kind0 = s2_kind(sidx), k_ = s2_idx(sidx);                                       \
+      constexpr int kind = W2_SKIPPED(kind0) ? 0 : kind0;                                           \
       if (kind == 1) {                      /* U(c+1): registers -> LDS */                         \
         if (k_ == 0) { SU1(uw_, 0, gu[0]); SU1(uw_, 1, gu[1]); SU1(uw_, 2, gu[2]); }                \
         else { SU1(uw_, 3, gu[3]); SU1(uw_, 4, gu[4]); }                                            \
       } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
-        Sraw1(rw_, k_ % NRAWQ, graw[k_ % NRAWQ]);                                                   \
+        Sraw1(rw_, k_ % NRAWQ, graw[k_ % NRAWQ], smask);                                            \
       } else if (kind == 2) {               /* patch load of chunk c+3 */                          \
-        Graw1(k_ % NRAWQ, rpy, rpx, rc0, graw[k_ % NRAWQ]);                                         \
+        Graw1(k_ % NRAWQ, xp_, graw[k_ % NRAWQ]);                                                   \
       } else if (kind == 3) {               /* weight load of chunk c+2 */                         \
-        GU1(k_ % NUQ, fu, gu[k_ % NUQ]);                                                            \
+        GU1(k_ % NUQ, up_, gu[k_ % NUQ]);                                                           \
       } else if (kind == 4) {               /* patch of chunk c+1: two float2 */                   \
         constexpr int i0 = 2 * (k_ % 9), i1 = i0 + 1;                                               \
         xv[i0 / 9][(i0 % 9) / 3][i0 % 3] = *(const f32x2*)(rb_ + (i0 / 9) * (8 * PC2 * 4) + (((i0 % 9) / 3) * PC2 + i0 % 3) * 4); \
         xv[i1 / 9][(i1 % 9) / 3][i1 % 3] = *(const f32x2*)(rb_ + (i1 / 9) * (8 * PC2 * 4) + (((i1 % 9) / 3) * PC2 + i1 % 3) * 4); \
       } else if (kind == 5) {               /* one row of V of one item */                         \
         Vrow(vw_, (k_ % 6) / 3, (k_ % 6) % 3);                                                      \
+      } else if (kind == 8) {               /* patch cursor -> f+4; graw now holds f+3 */          \
+        s_c0 = rcc * 8; smask = okm_cur;                                                            \
+        advance_raw();                                                                              \
+        xp_ = ximg + rcc * 32;                                                                      \
+        set_affine(s_c0);                                                                           \
+      } else if (kind == 9) {               /* U cursor -> f+3 */                                  \
+        if (advance(ku, cu)) set_u_tile(ku);                                                        \
+        up_ = uchunk_of(cu);                                                                        \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -335,24 +426,82 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     W2SLOT8(0) W2SLOT8(8) W2SLOT8(16) W2SLOT8(24) W2SLOT8(32) W2SLOT8(40) W2SLOT8(48) W2SLOT8(56) W2SLOT8(64)
 #undef W2SLOT8
 #undef W2SLOT
+#undef W2_STAMP
+#ifdef W2_PROF
+    st_[3] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                        // the only barrier of the chunk
+#ifdef W2_PROF
+    st_[4] = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef W2_PROF
+    st_[5] = __builtin_amdgcn_s_memtime();
+    if (MODE == 0 && a.bn_scale != nullptr && t == 0 && cm == (nchunk > 5 ? 5 : 0)) {      // MODE 0 hack: stamps of one chunk per tile
+      unsigned long long* sb = (unsigned long long*)a.bn_scale + ((size_t)blockIdx.x * 16 + (km & 15)) * 8;
+      for (int i = 0; i < 6; ++i) sb[i] = st_[i];
+    }
+#endif
   }
-
+  // ======== tile km is complete: drain the accumulators.  V[f&1] / U[f&1] (f = the tile's last position) and
+  // raw[(f+1)&1] were consumed; V / U[(f+1)&1] and raw[f&1] already hold the next tile's first chunks and must survive.
+  const int cl = c_next - 1;
+#ifdef W2_PROF
+  pf_t1 = clock64(); pf_loop += pf_t1 - pf_t0;
+  {
+    const TilePos q_ = tile_pos(km);
+    const bool tf = q_.Y0 >= 1 && q_.X0 >= 1 && SXY * (q_.Y0 + PR2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.H - 1 &&
+                    SXY * (q_.X0 + PC2 - 1) - 1 + (MODE == 0 ? 1 : 0) <= a.W - 1;
+    if (tf) { pf_ep2 += pf_t1 - pf_t0; pf_nfast += 1; }   // MODE 0 only: loop cycles and count of tiles inside the image
+  }
+#endif
+  const TilePos tp = tile_pos(km);
+  const int nb = tp.nb, b = tp.b, Y0 = tp.Y0, X0 = tp.X0;
+  float* ow = wave < 2 ? Vs + (cl & 1) * V2_BUF + wave * 4096 : wave == 2 ? Us + (cl & 1) * U2_BUF
+                                                                            : Rs + ((cl + 1) & 1) * RAW2_BUF;   // 16 KiB per wave
+  float* red = Vs + (cl & 1) * V2_BUF + 8192;     // [2 wm][64][2], behind the scratch of waves 0 and 1
   if (MODE == 1) {
-    // ---- input gradient: the same A^T M A; grid point (Yg, Xg) of q block nb = one (py, px) class and 64 channels of it
+    // ---- input gradient: the same A^T M A; grid point (Yg, Xg) of q block nb = one (py, px) class and 64 channels of it.
+    // One wave is alone on its SIMD: every instruction of this drain is exposed, so addresses are a uniform pointer per
+    // (half, step) plus ONE 32-bit lane offset, validity is two per-lane bit masks (none at all for tiles inside the
+    // image), and the BatchNorm z values of a half are requested before its output transform runs.
     const int q0 = nb * 64;
     const int ph = q0 / a.Cx, cb0 = q0 - ph * a.Cx, py = ph >> 1, px = ph & 1;
-    float* ow = smem + wave * 4096;
     const int c4 = lane & 7;
     const int cch = cb0 + wn * 32 + c4 * 4;               // first of this lane's 4 channels
     const bool bnb = a.bn_red != nullptr;
-    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bmu = bsc, bis = bsc, b1 = bsc, b2 = bsc;
+    f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bnm = bsc, bis = bsc, b1 = bsc, b2 = bsc;
     if (bnb) {
       bsc = *(const f32x4*)(a.bn_scale + cch); bsh = *(const f32x4*)(a.bn_shift + cch);
-      bmu = *(const f32x4*)(a.bn_mean + cch); bis = *(const f32x4*)(a.bn_invstd + cch);
+      bis = *(const f32x4*)(a.bn_invstd + cch);
+      bnm = -*(const f32x4*)(a.bn_mean + cch) * bis;      // xhat = z * invstd - mean * invstd
     }
+    // step `it` of half mi covers grid rows Y0 + 8 wm + 4 mi + 2 (it >> 3) + lr, columns X0 + 4 (it & 7) + lc
+    const int lr = (lane >> 4) & 1, lc = 2 * lh + ((lane >> 3) & 1);
+    const int rowstride = 2 * a.Wx * a.Cx, colstride = 2 * a.Cx;                       // floats per grid row / column
+    const unsigned lane_off = (unsigned)(lr * rowstride + lc * colstride + c4 * 4);
+    const long long tile_off = ((long long)b * a.Hx + (2 * (Y0 + 8 * wm) - 1 + py)) * a.Wx * a.Cx +
+                               (long long)(2 * X0 - 1 + px) * a.Cx + cb0 + wn * 32;   // uniform; rows above the image: masked
+    float* ytile = a.Y + tile_off;
+    const float* ztile = a.bn_z + tile_off;
+    // valid grid rows [rlo, rhi), columns [clo, chi) relative to the tile: iy = 2 Yg - 1 + py in [0, Hx) <=> 1 - py <= Yg < Ho - py
+    const int rlo = max(1 - py - Y0, 0), rhi = min(a.Ho - py - Y0, 16), clo = max(1 - px - X0, 0), chi = min(a.Wo - px - X0, 32);
+    const bool full = rlo == 0 && rhi == 16 && clo == 0 && chi == 32;                  // uniform
+    const unsigned rowmask = rhi > rlo ? ((0xffffu >> (16 - rhi + rlo)) << rlo) : 0u;
+    const unsigned colmask = chi > clo ? ((0xffffffffu >> (32 - chi + clo)) << clo) : 0u;
+    const unsigned myrows = rowmask >> (lr + 8 * wm), mycols = colmask >> lc;          // bit 4 mi + 2 (it >> 3) / 4 (it & 7)
+    auto half = [&](auto full_c, auto mi_c) {
+      constexpr bool FULL = decltype(full_c)::value;
+      constexpr int mi = decltype(mi_c)::value;
+      f32x4 zq_[16];
+      if (bnb) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+        for (int it = 0; it < 16; ++it) {
+          const bool ok = FULL || (((myrows >> (4 * mi + 2 * (it >> 3))) & (mycols >> (4 * (it & 7))) & 1u) != 0u);
+          const float* zp = ztile + (4 * mi + 2 * (it >> 3)) * rowstride + 4 * (it & 7) * colstride;
+          if (ok) zq_[it] = *(const f32x4*)(zp + lane_off);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tloc = (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -365,44 +514,44 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
         op[64] = (m[3] + m[4]) + (m[6] + m[7]); op[96] = (m[4] + m[5]) + (m[7] + m[8]);
         __builtin_amdgcn_sched_barrier(0);
       }
-      long long offs[16];
-      f32x4 zq_[16];
-#pragma unroll
-      for (int it = 0; it < 16; ++it) {                     // addresses, and all bn_z loads before the first use
-        const int p = it * 8 + (lane >> 3);
-        const int tl = wm * 64 + mi * 32 + (p >> 2), ab = p & 3;
-        const int Yg = Y0 + 2 * (tl >> 4) + (ab >> 1), Xg = X0 + 2 * (tl & 15) + (ab & 1);
-        const int iy = 2 * Yg - 1 + py, ix = 2 * Xg - 1 + px;
-        const bool ok = Yg < a.Ho && Xg < a.Wo && (unsigned)iy < (unsigned)a.Hx && (unsigned)ix < (unsigned)a.Wx;
-        offs[it] = ok ? (((long long)b * a.Hx + iy) * a.Wx + ix) * a.Cx + cch : -1;
-        if (bnb) zq_[it] = *(const f32x4*)(a.bn_z + (ok ? offs[it] : 0));
-      }
 #pragma unroll
       for (int it = 0; it < 16; ++it) {
         const int p = it * 8 + (lane >> 3);
         const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
-        if (offs[it] >= 0) {
-          *(f32x4*)(a.Y + offs[it]) = v;
+        const bool ok = FULL || (((myrows >> (4 * mi + 2 * (it >> 3))) & (mycols >> (4 * (it & 7))) & 1u) != 0u);
+        float* yp = ytile + (4 * mi + 2 * (it >> 3)) * rowstride + 4 * (it & 7) * colstride;
+        if (ok) {
+#ifdef W2_PROF
+          if (a.in_slope != 2.f)
+#endif
+          *(f32x4*)(yp + lane_off) = v;
           if (bnb) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-              const float y = zq_[it][k] * bsc[k] + bsh[k];
+              const float z = zq_[it][k];
+              const float y = __builtin_fmaf(z, bsc[k], bsh[k]);
               const float d = y > 0.f ? v[k] : v[k] * a.bn_slope;
               b1[k] += d;
-              b2[k] += d * ((zq_[it][k] - bmu[k]) * bis[k]);
+              b2[k] = __builtin_fmaf(d, __builtin_fmaf(z, bis[k], bnm[k]), b2[k]);
             }
           }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    constexpr std::integral_constant<int, 0> H0{};
+    constexpr std::integral_constant<int, 1> H1{};
+    if (full) { half(std::true_type{}, H0); half(std::true_type{}, H1); }
+    else { half(std::false_type{}, H0); half(std::false_type{}, H1); }
+#ifdef W2_PROF
+    pf_t2 = clock64(); pf_ep1 += pf_t2 - pf_t1;
+#endif
     if (bnb) {                               // lanes with the same channel quad, then the two waves with the same wn
 #pragma unroll
       for (int k = 0; k < 4; ++k)
 #pragma unroll
         for (int msk = 8; msk < 64; msk <<= 1) { b1[k] += __shfl_xor(b1[k], msk, 64); b2[k] += __shfl_xor(b2[k], msk, 64); }
-      __syncthreads();
-      float* bred = smem;                    // [2 wm][64][2]
+      float* bred = red;
       if (lane < 8) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -418,14 +567,12 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
         atomicAdd(rd + 2 * (cb0 + t) + 1, (double)bred[t * 2 + 1] + (double)bred[(64 + t) * 2 + 1]);
       }
     }
-    return;
-  }
+  } else {
   // ---- output transform (lane-local) Y = A^T M A, A^T = [[1,1,0],[0,1,1]], one 32-tile half of the wave at a time
   // through the wave's private 16 KiB of LDS (16-byte global stores), BatchNorm statistics from the same registers
   const int co = nb * 64 + wn * 32 + li;
   const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
-  float ssum = 0.f, ssq = 0.f;
-  float* ow = smem + wave * 4096;           // [pixel = tile*4 + 2a + b][32 channels]
+  float ssum = 0.f, ssq = 0.f;              // ow: [pixel = tile*4 + 2a + b][32 channels]
   const bool has_stats = a.stats != nullptr;
   const int oy0 = Y0, ox0 = X0;
   const int c4 = lane & 7;
@@ -475,9 +622,7 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
     }
     __builtin_amdgcn_sched_barrier(0);
   }
-  __syncthreads();                          // the statistics reduction below reuses the LDS
   if (has_stats) {
-    float* red = smem;                      // [2 wm][64][2]
     ssum += __shfl_xor(ssum, 32, 64);
     ssq += __shfl_xor(ssq, 32, 64);
     if (lh == 0) {
@@ -491,6 +636,20 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
       atomicAdd(st + 2 * (nb * 64 + t) + 1, (double)red[t * 2 + 1] + (double)red[(64 + t) * 2 + 1]);
     }
   }
+  }
+  __syncthreads();                          // scratch and `red` are rewritten by the next position's T / S_U / S_raw
+#ifdef W2_PROF
+  if (MODE == 1) pf_ep2 = clock64() - pf_t2;
+  else pf_ep1 += clock64() - pf_t1;
+#endif
+  }
+#ifdef W2_PROF
+  const void* pfp = MODE == 1 ? (const void*)a.bias : (const void*)a.bn_red;
+  if (pfp != nullptr && t == 0) {
+    long long* pf = (long long*)pfp + blockIdx.x * 4;
+    pf[0] = pf_loop; pf[1] = pf_ep1; pf[2] = pf_ep2; pf[3] = ntile_mine | (pf_nfast << 32);
+  }
+#endif
 }
 
 // U[chunk f = (py*2+px) * Cin/8 + c/8][xi = i*3+j][kq][co (Np)][e] = (G g' G^T)[i][j] for c = (f % (Cin/8)) * 8 + kq*4 + e,
@@ -892,6 +1051,16 @@ extern "C" int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin
   return 0;
 }
 
+// persistent grid: one block per CU (153 KB of LDS, 512 registers per lane)
+static int wino2_persistent_blocks(long long tiles, long long* blocks, const char* who) {
+  int dev = 0, ncu = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "%s: cannot query the CU count: %s", who, hipGetErrorString(he));
+  *blocks = tiles < ncu ? tiles : ncu;
+  return 0;
+}
+
 extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
                                      const float* in_scale, const float* in_shift, float in_slope, int B, int H,
                                      int W, int Cin, int Cout, void* stream) {
@@ -909,14 +1078,23 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   a.Np = (Cout + 63) / 64 * 64;
   a.Ho = H / 2; a.Wo = W / 2;
   a.tbh = (a.Ho + 2 * TR2 - 1) / (2 * TR2); a.tbw = (a.Wo + 2 * TC2 - 1) / (2 * TC2);
-  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / 64);
-  CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd: grid too large");
+  const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / 64);
+  CY_REQUIRE(tiles < (1ll << 31), "cy_conv4x4s2_winograd: too many tiles");
+  a.ntiles = (int)tiles;
+  long long blocks = 0;
+  int rcq = wino2_persistent_blocks(tiles, &blocks, "cy_conv4x4s2_winograd");
+  if (rcq) return rcq;
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF + (in_scale ? 2 * Cin : 0)) * 4;
   CY_REQUIRE(lds <= 160 * 1024, "cy_conv4x4s2_winograd: Cin=%d too large for the fused input affine", Cin);
   a.Hx = a.Wx = a.Cx = 0; a.bn_z = a.bn_scale = a.bn_shift = a.bn_mean = a.bn_invstd = nullptr; a.bn_red = nullptr; a.bn_slope = 0.f;
-  int rc = cy_allow_lds(wino2_conv_kernel<0>, lds);
+#ifdef W2_PROF
+  if (const char* e = getenv("CY_W2_PROF")) a.bn_red = (double*)strtoull(e, nullptr, 0);
+  if (const char* e = getenv("CY_W2_STAMPS")) a.bn_scale = (const float*)strtoull(e, nullptr, 0);
+#endif
+  int rc = in_scale ? cy_allow_lds(wino2_conv_kernel<0, true>, lds) : cy_allow_lds(wino2_conv_kernel<0, false>, lds);
   if (rc) return rc;
-  wino2_conv_kernel<0><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  if (in_scale) wino2_conv_kernel<0, true><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else wino2_conv_kernel<0, false><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd");
   return 0;
 }
@@ -985,7 +1163,13 @@ extern "C" int cy_conv4x4s2_winograd_dgrad(const float* dZ, const float* U, floa
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd_dgrad: image too large for 32-bit offsets");
   Wino2Args a;
   a.X = dZ; a.U = U; a.Y = dX; a.bias = nullptr; a.stats = nullptr;
+#ifdef W2_PROF
+  if (const char* e = getenv("CY_W2_PROF")) a.bias = (const float*)strtoull(e, nullptr, 0);
+#endif
   a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
+#ifdef W2_PROF
+  if (getenv("CY_W2_NOSTORE")) a.in_slope = 2.f;
+#endif
   a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout;          // the kernel's "input" is dY [B][H/2][W/2][Cout]
   a.Cout = 4 * Cin; a.Np = 4 * Cin;
   a.Ho = H / 2 + 1; a.Wo = W / 2 + 1;                       // grid of the space-to-depth view
@@ -993,12 +1177,16 @@ extern "C" int cy_conv4x4s2_winograd_dgrad(const float* dZ, const float* U, floa
   a.Hx = H; a.Wx = W; a.Cx = Cin;
   a.bn_z = bn_z; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
   a.bn_red = bn_red; a.bn_slope = bn_slope;
-  const long long blocks = (long long)B * a.tbh * a.tbw * (a.Np / 64);
-  CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_dgrad: grid too large");
+  const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / 64);
+  CY_REQUIRE(tiles < (1ll << 31), "cy_conv4x4s2_winograd_dgrad: too many tiles");
+  a.ntiles = (int)tiles;
+  long long blocks = 0;
+  int rcq = wino2_persistent_blocks(tiles, &blocks, "cy_conv4x4s2_winograd_dgrad");
+  if (rcq) return rcq;
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + 2 * RAW2_BUF) * 4;
-  int rc = cy_allow_lds(wino2_conv_kernel<1>, lds);
+  int rc = cy_allow_lds(wino2_conv_kernel<1, false>, lds);
   if (rc) return rc;
-  wino2_conv_kernel<1><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  wino2_conv_kernel<1, false><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_dgrad");
   return 0;
 }

@@ -9,7 +9,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // KIND: 0 none, 1 ds_write_b128, 2 ds_read_b128, 3 global dwordx4 coalesced (1 KB per wave), 4 global dwordx4 in
 // 32-byte pieces 512 B apart (32 cache lines per wave), 5 ds_write_b64, 6 ds_read_b64 stride 32 B (8-way conflict),
-// 7 v_pk_add_f32 x4, 8 v_add_f32 x4, 9 ds_read_b64 contiguous
+// 7 v_pk_add_f32 x4, 8 v_add_f32 x4, 9 ds_read_b64 contiguous, 10 global dwordx4 coalesced with a uniform base + 32-bit
+// lane offset, 11 global -> LDS direct dwordx4 (no VGPR destination), 12 the same in 32-byte pieces
 template <int KIND, int EVERY>
 __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters, float a, float b) {
   __shared__ __attribute__((aligned(16))) float lds[8192];
@@ -22,6 +23,7 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
   const f32x4* gco = (const f32x4*)in + t + (blockIdx.x & 63) * 4096;
   const f32x4* gsc = (const f32x4*)in + (t >> 1) * 32 + (t & 1) + (blockIdx.x & 63) * 4096;
   float* lw = lds + t * 4;
+  const unsigned voff = t * 16;
   float* lr8 = lds + (t & 63) * 8;
   float* lr2 = lds + (t & 63) * 2;
   for (int i = 0; i < iters; ++i) {
@@ -37,6 +39,11 @@ __global__ __launch_bounds__(256) void k(float* out, const float* in, int iters,
         if (KIND == 5) *(f32x2*)(lw + 1024 * (u & 3)) = f32x2{ring[u][0], ring[u][1]};
         if (KIND == 6) { sum[0] += ring[u][0]; f32x2 r = *(volatile f32x2*)(lr8 + 1024 * (u & 3)); ring[u][0] = r[0] + r[1]; }
         if (KIND == 9) { sum[0] += ring[u][0]; f32x2 r = *(volatile f32x2*)(lr2 + 1024 * (u & 3)); ring[u][0] = r[0] + r[1]; }
+        if (KIND == 10) { sum += ring[u]; ring[u] = *(const f32x4*)((const char*)in + (blockIdx.x & 63) * 65536 + 4096 * ((i * 16 + u) & 15) + voff); }
+        if (KIND == 11) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gco + 256 * ((i * 16 + u) & 15)),
+                                                         (__attribute__((address_space(3))) void*)(lds + 1024 * (u & 3) + 256 * (t >> 6)), 16, 0, 0);
+        if (KIND == 12) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gsc + 2 * ((i * 16 + u) & 7)),
+                                                         (__attribute__((address_space(3))) void*)(lds + 1024 * (u & 3) + 256 * (t >> 6)), 16, 0, 0);
         if (KIND == 7) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(pv[q]) : "v"(pv[q]), "v"(pv[(q + 1) & 3]));
@@ -84,6 +91,12 @@ int main() {
   run<3, 4>(out, in, nb, "global_load_dwordx4 coalesced");
   run<4, 1>(out, in, nb, "global_load_dwordx4 32 B pieces");
   run<4, 4>(out, in, nb, "global_load_dwordx4 32 B pieces");
+  run<10, 1>(out, in, nb, "global_load_dwordx4 coalesced, saddr + voffset");
+  run<10, 4>(out, in, nb, "global_load_dwordx4 coalesced, saddr + voffset");
+  run<11, 1>(out, in, nb, "global_load_lds_dwordx4 coalesced");
+  run<11, 4>(out, in, nb, "global_load_lds_dwordx4 coalesced");
+  run<12, 1>(out, in, nb, "global_load_lds_dwordx4 32 B pieces");
+  run<12, 4>(out, in, nb, "global_load_lds_dwordx4 32 B pieces");
   run<0, 1>(out, in, nb, "none", 2);
   run<3, 1>(out, in, nb, "global_load_dwordx4 coalesced", 2);
   run<3, 4>(out, in, nb, "global_load_dwordx4 coalesced", 2);
