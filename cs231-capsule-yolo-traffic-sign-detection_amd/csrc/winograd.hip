@@ -26,6 +26,10 @@ constexpr int VU_BUF = 32 * SLAB;           // 16 positions x 2 k-quads
 constexpr int RAWP = 337;                   // 18*18 = 324 pixels, padded: the k-quad stride is 4 banks (mod 64)
 constexpr int RAW_BUF = 2 * RAWP * 4;       // [kq][pixel][4]
 
+// zeros that padding items of a patch are loaded from (the chunk offset, < 4 Cin bytes, is added to every item's pointer)
+constexpr int WINO_MAX_CIN = 2048;
+__device__ __attribute__((aligned(256))) float wino_zero_pad[WINO_MAX_CIN];
+
 struct WinoArgs {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
   int B, H, W, Cin, Cout, Np, tbh, tbw;
@@ -157,30 +161,30 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   // raw patch: 648 float4 items over 256 threads x 3; 32 consecutive items = 16 pixels x 2 k-quads with the pixel in
   // the low 4 bits, so that the 16 lanes of one ds_write_b128 pass hit 16 different pixels of one k-quad (no bank
   // conflict) while a wave's global load still covers both 16-byte halves of each pixel's 32 bytes
-  long long goff[3]; bool gok[3]; int roff[3];
-  unsigned gvoff[3];                        // fast path: byte offset from the image's first pixel (tile inside the image)
-  bool blk_fast = false;                    // uniform
-  const char* ximg = nullptr;               // uniform
-  int rpy[3], rpx[3]; bool rvalid[3];
+  // No branch and no exec mask may stand in the MFMA slots (a uniform branch costs this one-wave-per-SIMD loop ~40
+  // cycles): every item has ONE 64-bit lane pointer per tile -- its pixel, or, for padding, a block of zeros
+  // (wino_zero_pad) -- so loads and LDS stores are unconditional.  The third round is partial (pixels 256..323 only):
+  // the other threads repeat their second item (same address, same LDS slot, same value).
+  const char* gptr[3];                      // channel 0 of the item's k-quad in the tile the patch stream is in
+  int roff[3];
+  int rpy[3], rpx[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const int item = t + 256 * q;
+    const int pix2 = ((t + 512) >> 5) * 16 + (t & 15);               // pixel of the third item: only 324 exist
+    const int item = t + 256 * ((q < 2 || pix2 < 324) ? q : 1);
     const int pix = (item >> 5) * 16 + (item & 15), kq = (item >> 4) & 1;
-    rvalid[q] = pix < 324;
     rpy[q] = pix / 18; rpx[q] = pix - rpy[q] * 18;
-    roff[q] = rvalid[q] ? (kq * RAWP + pix) * 4 : -1;
+    roff[q] = (kq * RAWP + pix) * 4;
   }
+  const int kq_of_thread = (t >> 4) & 1;    // 256 q keeps bit 4 of the item
   auto set_raw_tile = [&](int k) {
     const TilePos p = tile_pos(k);
-    blk_fast = p.oy0 >= 1 && p.ox0 >= 1 && p.oy0 + 17 <= a.H && p.ox0 + 17 <= a.W;
-    ximg = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin);
+    const char* img = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin) + kq_of_thread * 16;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      const int kq = ((t + 256 * q) >> 4) & 1;
       const int iy = p.oy0 - 1 + rpy[q], ix = p.ox0 - 1 + rpx[q];
-      gok[q] = rvalid[q] && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      goff[q] = (((long long)p.b * a.H + iy) * a.W + ix) * a.Cin + kq * 4;
-      gvoff[q] = (blk_fast && rvalid[q]) ? (unsigned)(((iy * a.W + ix) * a.Cin + kq * 4) * 4) : 0u;
+      const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+      gptr[q] = ok ? img + (size_t)((iy * a.W + ix) * a.Cin) * 4 : (const char*)wino_zero_pad + kq_of_thread * 16;
     }
   };
   // stream cursors (tile index within this block, chunk): advance by one chunk, stop at the very last chunk
@@ -210,14 +214,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   // chunk body stays straight-line code and hipcc's vmcnt counts stay exact)
   auto Graw = [&](int c, f32x4 (&dst)[3]) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
-      if (blk_fast) {
-        dst[q] = *(const f32x4*)(ximg + (size_t)c * (KC * 4) + gvoff[q]);
-      } else {
-        const f32x4 v = *(const f32x4*)(a.X + ((gok[q] ? goff[q] : 0ll) + (long long)c * KC));
-        dst[q] = gok[q] ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
+    for (int q = 0; q < 3; ++q) dst[q] = *(const f32x4*)(gptr[q] + (size_t)c * (KC * 4));
   };
   auto GU = [&](int c, f32x4 (&dst)[8]) {
 #pragma unroll
@@ -226,8 +223,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   auto Sraw = [&](int c, const f32x4 (&src)[3]) {   // registers -> LDS raw patch buffer c & 1
     float* rb = Rs + (c & 1) * RAW_BUF;
 #pragma unroll
-    for (int q = 0; q < 3; ++q)
-      if (roff[q] >= 0) *(f32x4*)(rb + roff[q]) = src[q];
+    for (int q = 0; q < 3; ++q) *(f32x4*)(rb + roff[q]) = src[q];
   };
   auto SU = [&](int c, const f32x4 (&src)[8]) {     // registers -> LDS U buffer c & 1
     float* ub = Us + (c & 1) * VU_BUF;
@@ -319,8 +315,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     const float* ub_ = Us + (c & 1) * VU_BUF + fragB;
     const float* rb_ = Rs + ((c + 1) & 1) * RAW_BUF + tbase;        // T(f+1) reads ...
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last position)
-    const long long gx = (long long)cr * KC;                        // G_raw(f+3) (the cursors stop at the last position:
-    const char* gxfast = ximg + (size_t)cr * (KC * 4);              //  the tail re-loads valid data), uniform
+    const size_t gx = (size_t)cr * (KC * 4);                        // G_raw(f+3) (the cursors stop at the last position:
+                                                                    //  the tail re-loads valid data), uniform
     const char* gusrc = ubase + (long long)cu * uchunk * 4;         // G_U(f+2), uniform
     float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(f+1) (harmless after the last position)
     float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(f+2) -> raw[(f+2)&1]
@@ -345,12 +341,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       if (kind == 1) {                      /* U(c+1): registers -> LDS, one float4 per piece */   \
         *(f32x4*)(uw_ + k_ * 4 * SLAB) = gu[k_];                                                    \
       } else if (kind == 2) {               /* patch loads of chunk c+3 */                         \
-        if (blk_fast) {                                                                             \
-          graw[k_] = *(const f32x4*)(gxfast + gvoff[k_]);                                           \
-        } else {                                                                                    \
-          const f32x4 v_ = *(const f32x4*)(a.X + ((gok[k_] ? goff[k_] : 0ll) + gx));                \
-          graw[k_] = gok[k_] ? v_ : f32x4{0.f, 0.f, 0.f, 0.f};                                      \
-        }                                                                                           \
+        graw[k_] = *(const f32x4*)(gptr[k_] + gx);                                                  \
       } else if (kind == 3) {               /* weight loads of chunk c+2 */                        \
         gu[k_] = *(const f32x4*)(gusrc + k_ * (useg * 4) + uvoff);                                  \
       } else if (kind == 4) {               /* patch of chunk c+1: two float2 */                   \
@@ -360,8 +351,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       } else if (kind == 5) {               /* half a row of V */                                  \
         Vhalf(vw_, wino_row_order((k_ >> 1) & 3), k_ & 1);                                          \
       } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
-        if (k_ < 2) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                           \
-        else if (roff[k_] >= 0) *(f32x4*)(rw_ + roff[k_]) = graw[k_];                               \
+        *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                                       \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -908,6 +898,7 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
                                    int W, int Cin, int Cout, void* stream) {
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv3x3_winograd: bad arguments");
   CY_REQUIRE(Cin % KC == 0 && Cin >= KC, "cy_conv3x3_winograd: Cin=%d must be a multiple of %d", Cin, KC);
+  CY_REQUIRE(Cin <= WINO_MAX_CIN, "cy_conv3x3_winograd: Cin=%d exceeds %d", Cin, WINO_MAX_CIN);
   CY_REQUIRE((((uintptr_t)X | (uintptr_t)U) & 15) == 0, "cy_conv3x3_winograd: operands must be 16-byte aligned");
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29) && (long long)H * W * Cout < (1ll << 29),
              "cy_conv3x3_winograd: image too large for 32-bit byte offsets");
