@@ -769,15 +769,33 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
 
   const int fragA = lh * SLAB + (wm * 32 + li) * 4;
   const int fragB = lh * SLAB + (wn * 32 + li) * 4;
+  // position (image, group row, group column) of the chunk whose loads are in flight: chunk min(c + 3, nchunk - 1),
+  // stepped without divisions
+  int ggb, ggy, ggx;
+  {
+    const int cg = cbeg + (nchunk > 2 ? 2 : nchunk - 1);
+    ggb = cg / ngroups;
+    const int ggr = cg - ggb * ngroups;
+    ggy = ggr / a.gw; ggx = ggr - ggy * a.gw;
+  }
   for (int c = 0; c < nchunk; ++c) {
     const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
     const float* ub_ = Zs + (c & 1) * VU_BUF + fragB;
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // T(c+1) (harmless after the last chunk)
     float* zw_ = Zs + ((c + 1) & 1) * VU_BUF + vdst;
-    const int cg = cbeg + ((c + 3 < nchunk) ? c + 3 : nchunk - 1);
-    const int ggb = cg / ngroups, ggr = cg - ggb * ngroups;
-    const int ggy = ggr / a.gw, ggx = ggr - ggy * a.gw;
+    if (c + 3 < nchunk) {                                           // uniform; the tail re-loads the last chunk
+      const bool wx = ggx + 1 == a.gw;
+      ggx = wx ? 0 : ggx + 1;
+      const bool wy = wx && ggy + 1 == a.gh;
+      ggy = wy ? 0 : ggy + (wx ? 1 : 0);
+      ggb += wy ? 1 : 0;
+    }
+    // The MFMA slots hold no branch: a chunk inside the image loads `uniform patch origin + lane offset`; a chunk at
+    // the border loads a harmless valid address there and is re-loaded, with bounds, after the stream; LDS stores are
+    // unconditional and the padding of a border chunk is zeroed in LDS after the stream.
     const bool gf_next = is_fast(ggy, ggx);
+    const char* xb_ = xall + (gf_next ? ggb * ximgb + (size_t)(((ggy * 4 - 1) * a.W + ggx * 8 - 1) * a.Cin) * 4 : (size_t)0);
+    const char* zb_ = zall + (gf_next ? ggb * zimgb + (size_t)((ggy * 4 * a.W + ggx * 8) * a.Cout) * 4 : (size_t)0);
     f32x4 fa_[4], fb_[4];
     fa_[0] = *(const f32x4*)(vb_);
     fb_[0] = *(const f32x4*)(ub_);
@@ -797,8 +815,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
       }                                                                                             \
       constexpr int kind = wg_side_kind(sidx), k_ = wg_side_idx(sidx) >= 0 ? wg_side_idx(sidx) : 0; \
       if (kind == 1) {                      /* one global load of chunk c+3 */                     \
-        if (k_ < 4) Gx(k_ & 3, ggb, ggy, ggx, gf_next); else Gz(k_ & 1, ggb, ggy, ggx, gf_next);              \
-        if (k_ == 5) gfast = gf_next;                                                               \
+        if (k_ < 4) gx[k_ & 3] = *(const f32x4*)(xb_ + (gf_next ? voffx[k_ & 3] : (unsigned)(c4 * 16)));     \
+        else gz[k_ & 1] = *(const f32x4*)(zb_ + (gf_next ? voffz[k_ & 1] : (unsigned)(c4 * 16)));   \
       } else if (kind == 2) {               /* raw patches of chunk c+1: 2 pairs */                \
         if (k_ < 2) {                                                                               \
           constexpr int r = k_ & 1;                                                                 \
@@ -818,7 +836,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
       } else if (kind == 6) {               /* all waves are past their raw-patch reads */         \
         __builtin_amdgcn_s_barrier();                                                               \
       } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
-        if (k_ < 4) Sx(k_ & 3); else Sz(k_ & 1);                                                    \
+        if (k_ < 4) *(f32x4*)(Rw + (prow + 16 * (k_ & 3)) * 64 + c4 * 4) = gx[k_ & 3];              \
+        else *(f32x4*)(Rw + (XPS + prow + 16 * (k_ & 1)) * 64 + c4 * 4) = gz[k_ & 1];               \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -828,6 +847,23 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
 #undef WGSLOT16
 #undef WGSLOT4
 #undef WGSLOT
+    if (!(gfast && gf_next)) {              // uniform, border chunks only
+      if (!gfast) {                         // the patch just stored: zero its padding (okm of its load)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (!((okm >> q) & 1)) *(f32x4*)(Rw + (prow + 16 * q) * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (!((okm >> (4 + q)) & 1)) *(f32x4*)(Rw + (XPS + prow + 16 * q) * 64 + c4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!gf_next) {                       // the patch just requested: load it again with bounds
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Gx(q, ggb, ggy, ggx, false);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Gz(q, ggb, ggy, ggx, false);
+      }
+    }
+    gfast = gf_next;
     __syncthreads();
   }
 
