@@ -750,6 +750,7 @@ constexpr int g2_between(int from, int to) {
   return n > 14 ? 14 : n;
 }
 
+template <bool AFFINE>
 __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][V2_BUF]   A images (X', rows = q)
@@ -817,7 +818,7 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
       okm = (okm & ~(64u << q)) | ((unsigned)ok << (6 + q));
     }
   };
-  const bool affine = a.in_scale != nullptr;      // uniform; this thread's 4 input channels never change
+  constexpr bool affine = AFFINE;           // this thread's 4 input channels never change
   const f32x4 asc = affine ? *(const f32x4*)(a.in_scale + qc) : f32x4{1.f, 1.f, 1.f, 1.f};
   const f32x4 ash = affine ? *(const f32x4*)(a.in_shift + qc) : f32x4{0.f, 0.f, 0.f, 0.f};
   auto Sx = [&](int q) {
@@ -912,14 +913,27 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
 
   const int fragA = lh * SLABV + (wm * 64 + li) * 4;
   const int fragB = lh * SLABU + (wn * 32 + li) * 4;
+  int ggy, ggx;                             // group of the chunk whose loads are in flight: chunk min(c + 3, nchunk - 1)
+  {
+    const int cg = cbeg + (nchunk > 2 ? 2 : nchunk - 1);
+    ggy = cg / a.gw; ggx = cg - ggy * a.gw;
+  }
   for (int c = 0; c < nchunk; ++c) {
     const float* vb_ = Vs + (c & 1) * V2_BUF + fragA;
     const float* ub_ = Zs + (c & 1) * U2_BUF + fragB;
     float* vw_ = Vs + ((c + 1) & 1) * V2_BUF + vdst;                // transforms of chunk c+1 (harmless after the last chunk)
     float* zw_ = Zs + ((c + 1) & 1) * U2_BUF + zdst;
-    const int cg = cbeg + ((c + 3 < nchunk) ? c + 3 : nchunk - 1);
-    const int ggy = cg / a.gw, ggx = cg - ggy * a.gw;
+    if (c + 3 < nchunk) {                                           // uniform; the tail re-loads the last chunk
+      const bool wx = ggx + 1 == a.gw;
+      ggx = wx ? 0 : ggx + 1;
+      ggy += wx ? 1 : 0;
+    }
+    // No branch in the MFMA slots (winograd.hip, weight gradient): chunks inside the image load `uniform origin + lane
+    // offset`, border chunks load a harmless valid address there and are re-loaded with bounds after the stream; LDS
+    // stores are unconditional and a border chunk's padding is zeroed in LDS after the stream.
     const bool gf_next = is_fast(ggy, ggx);
+    const char* xb_ = ximg + (gf_next ? (size_t)(((8 * ggy - 1) * a.W + (16 * ggx - 1)) * a.Cin) * 4 : (size_t)0);
+    const char* zb_ = zimg + (gf_next ? (size_t)((4 * ggy * a.Wo + 8 * ggx) * a.Cout) * 4 : (size_t)0);
     f32x4 fa_[2][2], fb_[2];
     fa_[0][0] = *(const f32x4*)(vb_);
     fa_[0][1] = *(const f32x4*)(vb_ + 128);
@@ -937,14 +951,14 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
         if (w_ == 1) fa_[nx & 1][1] = *(const f32x4*)(vb_ + nx * 2 * SLABV + 128);                  \
         if (w_ == 2) fb_[nx & 1] = *(const f32x4*)(ub_ + nx * 2 * SLABU);                           \
       }                                                                                             \
-      constexpr int kind = g2_kind(sidx), k_ = g2_idx(sidx);                                        \
+      constexpr int kind = g2_kind(sidx), k_ = g2_idx(sidx) < 0 ? 0 : g2_idx(sidx);                 \
       if (kind == 4) {                      /* raw patches of chunk c+1: two pairs */              \
         if (k_ < 2) {                                                                               \
           constexpr int r = k_ & 1;                                                                 \
           zv[r][0] = lds_pair_st64<r * 8 + 0, r * 8 + 2>(zr_a);                                     \
           zv[r][1] = lds_pair_st64<r * 8 + 1, r * 8 + 3>(zr_a);                                     \
         } else {                                                                                    \
-          constexpr int i0 = 2 * ((k_ - 2) % 9), i1 = i0 + 1;          /* 18 pairs: (item, row, col) */ \
+          constexpr int i0 = 2 * ((k_ < 2 ? 0 : k_ - 2) % 9), i1 = i0 + 1;   /* 18 pairs: (item, row, col) */ \
           constexpr int p0 = ((i0 % 9) / 3) * 9 + 4 * (i0 / 9) + i0 % 3, p1 = ((i1 % 9) / 3) * 9 + 4 * (i1 / 9) + i1 % 3; \
           xv[i0 / 9][(i0 % 9) / 3][i0 % 3] = lds_pair_st64<2 * p0, 2 * p0 + 4>(xr_a);               \
           xv[i1 / 9][(i1 % 9) / 3][i1 % 3] = lds_pair_st64<2 * p1, 2 * p1 + 4>(xr_a);               \
@@ -958,10 +972,12 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
       } else if (kind == 8) {               /* all waves are past their raw-patch reads */         \
         __builtin_amdgcn_s_barrier();                                                               \
       } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
-        if (k_ < 6) Sx(k_ % 6); else Sz(k_ & 1);                                                    \
+        if (k_ < 6) *(f32x4*)(Rw + (xprow + 8 * (k_ % 6)) * WQ + xc4 * 4) =                         \
+            affine ? affine_lrelu4(gx[k_ % 6], asc, ash, a.in_slope) : gx[k_ % 6];                  \
+        else *(f32x4*)(Rw + XPWS * WQ + (zprow + 16 * (k_ & 1)) * 64 + zc4 * 4) = gz[k_ & 1];       \
       } else if (kind == 2) {               /* one global load of chunk c+3 */                     \
-        if (k_ < 6) Gx(k_ % 6, ggy, ggx, gf_next); else Gz(k_ & 1, ggy, ggx, gf_next);              \
-        if (k_ == 7) gfast = gf_next;                                                               \
+        if (k_ < 6) gx[k_ % 6] = *(const f32x4*)(xb_ + (gf_next ? voffx[k_ % 6] : (unsigned)(qc * 4)));      \
+        else gz[k_ & 1] = *(const f32x4*)(zb_ + (gf_next ? voffz[k_ & 1] : (unsigned)(zc4 * 16)));  \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -969,6 +985,23 @@ __global__ __launch_bounds__(256, 1) void wino2_wgrad_kernel(Wino2WgradArgs a) {
     G2SLOT8(0) G2SLOT8(8) G2SLOT8(16) G2SLOT8(24) G2SLOT8(32) G2SLOT8(40) G2SLOT8(48) G2SLOT8(56) G2SLOT8(64)
 #undef G2SLOT8
 #undef G2SLOT
+    if (!(gfast && gf_next)) {              // uniform, border chunks only
+      if (!gfast) {                         // the patch just stored: zero its padding (okm of its load)
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+          if (!((okm >> q) & 1)) *(f32x4*)(Rw + (xprow + 8 * q) * WQ + xc4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          if (!((okm >> (6 + q)) & 1)) *(f32x4*)(Rw + XPWS * WQ + (zprow + 16 * q) * 64 + zc4 * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if (!gf_next) {                       // the patch just requested: load it again with bounds
+#pragma unroll
+        for (int q = 0; q < 6; ++q) Gx(q, ggy, ggx, false);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) Gz(q, ggy, ggx, false);
+      }
+    }
+    gfast = gf_next;
     __syncthreads();
   }
 
@@ -1130,10 +1163,11 @@ extern "C" int cy_conv4x4s2_winograd_wgrad(const float* X, const float* dZ, floa
   const long long blocks = (long long)B * a.nsplit * (4 * Cin / WQ) * (Cout / 64);
   CY_REQUIRE(blocks < (1ll << 31), "cy_conv4x4s2_winograd_wgrad: grid too large");
   const size_t lds = (size_t)(2 * V2_BUF + 2 * U2_BUF + RAWG_BUF) * 4;
-  int rc = cy_allow_lds(wino2_wgrad_kernel, lds);
+  int rc = in_scale ? cy_allow_lds(wino2_wgrad_kernel<true>, lds) : cy_allow_lds(wino2_wgrad_kernel<false>, lds);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  wino2_wgrad_kernel<<<(unsigned)blocks, 256, lds, s>>>(a);
+  if (in_scale) wino2_wgrad_kernel<true><<<(unsigned)blocks, 256, lds, s>>>(a);
+  else wino2_wgrad_kernel<false><<<(unsigned)blocks, 256, lds, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd_wgrad");
   const long long n = (long long)4 * Cin * Cout;
   wino2_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, B * a.nsplit, Cin, Cout);
