@@ -91,6 +91,7 @@ constexpr int WS_SU[8] = {10, 11, 12, 13, 14, 15, 18, 19};
 constexpr int WS_GU[8] = {20, 22, 26, 28, 30, 34, 36, 38};
 constexpr int WS_TRD[8] = {21, 23, 27, 29, 31, 35, 37, 39};
 constexpr int WS_TV[8] = {42, 43, 44, 45, 46, 47, 50, 51};
+constexpr int WS_BAR = 54;                  // barrier; the fragments of the next chunk's positions 0 / 1 follow in slots 56 / 57
 constexpr int wino_side_kind(int s) {
   return wino_find(WS_SU, 8, s) >= 0 ? 1 : wino_find(WS_GRAW, 3, s) >= 0 ? 2 : wino_find(WS_GU, 8, s) >= 0 ? 3
        : wino_find(WS_TRD, 8, s) >= 0 ? 4 : wino_find(WS_TV, 8, s) >= 0 ? 5 : wino_find(WS_SRAW, 3, s) >= 0 ? 7 : 0;
@@ -302,7 +303,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   // ONE piece is placed after each MFMA in program order (pinned with sched_barrier).  LDS operations complete in
   // order, so the fragments of position xi+1 (read right after position xi's first MFMA) are ready when
   // `lgkmcnt(N)` is checked.
+  // The chunk's barrier stands at slot WS_BAR, not at the end: by then every wave has issued all its reads of
+  // V/U[f&1] (the last fragments are fetched in slot 49) and all its writes of V/U[(f+1)&1] and raw; the MFMAs of the
+  // remaining slots need nothing from LDS, and under them the first two fragment sets of position f+1 are fetched,
+  // so that neither the barrier skew nor an LDS round trip stands between two chunks.
   int c_next = 0;                           // stream position f (only its parity is used)
+  f32x4 fa_[4], fb_[4];                     // fragment sets, indexed by position & 3; [0], [1] are loaded a chunk ahead
+  fa_[0] = *(const f32x4*)(Vs + fragA);
+  fb_[0] = *(const f32x4*)(Us + fragB);
+  fa_[1] = *(const f32x4*)(Vs + fragA + 2 * SLAB);
+  fb_[1] = *(const f32x4*)(Us + fragB + 2 * SLAB);
   for (km = 0; km < ntile_mine; ++km) {
   f32x16 acc[16];
 #pragma unroll
@@ -320,11 +330,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     const char* gusrc = ubase + (long long)cu * uchunk * 4;         // G_U(f+2), uniform
     float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uoff;                // S_U(f+1) (harmless after the last position)
     float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(f+2) -> raw[(f+2)&1]
-    f32x4 fa_[4], fb_[4];                   // fragment sets, indexed by position & 3
-    fa_[0] = *(const f32x4*)(vb_);
-    fb_[0] = *(const f32x4*)(ub_);
-    fa_[1] = *(const f32x4*)(vb_ + 2 * SLAB);
-    fb_[1] = *(const f32x4*)(ub_ + 2 * SLAB);
+    const float* vn_ = Vs + ((c + 1) & 1) * VU_BUF + fragA;         // fragments of position f+1
+    const float* un_ = Us + ((c + 1) & 1) * VU_BUF + fragB;
 #define WSLOT(SIDX)                                                                                 \
     {                                                                                               \
       constexpr int sidx = (SIDX);                                                                  \
@@ -352,6 +359,15 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
         Vhalf(vw_, wino_row_order((k_ >> 1) & 3), k_ & 1);                                          \
       } else if (kind == 7) {               /* patch of chunk c+2: registers -> LDS */             \
         *(f32x4*)(rw_ + roff[k_]) = graw[k_];                                                       \
+      } else if (sidx == WS_BAR) {          /* the only barrier of the chunk */                    \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        __builtin_amdgcn_s_barrier();                                                               \
+      } else if (sidx == WS_BAR + 2) {      /* positions 12, 13 are done with sets 0 and 1 */      \
+        fa_[0] = *(const f32x4*)(vn_);                                                              \
+        fb_[0] = *(const f32x4*)(un_);                                                              \
+      } else if (sidx == WS_BAR + 3) {                                                              \
+        fa_[1] = *(const f32x4*)(vn_ + 2 * SLAB);                                                   \
+        fb_[1] = *(const f32x4*)(un_ + 2 * SLAB);                                                   \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -361,7 +377,6 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
 #undef WSLOT16
 #undef WSLOT4
 #undef WSLOT
-    __syncthreads();                        // the only barrier of the chunk
     if (advance(kr, cr)) set_raw_tile(kr);
     if (advance(ku, cu)) set_u_tile(ku);
   }
