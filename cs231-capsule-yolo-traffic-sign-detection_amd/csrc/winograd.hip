@@ -36,6 +36,11 @@ struct WinoArgs {
   int ntiles;                               // B * tbh * tbw * Np/64 output tiles, walked by a persistent grid
 };
 
+__device__ __forceinline__ f32x16 mfma_zero() {
+  f32x16 c;
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %1, 0" : "=a"(c) : "v"(0.f));
+  return c;
+}
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
@@ -313,12 +318,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   fb_[0] = *(const f32x4*)(Us + fragB);
   fa_[1] = *(const f32x4*)(Vs + fragA + 2 * SLAB);
   fb_[1] = *(const f32x4*)(Us + fragB + 2 * SLAB);
-  for (km = 0; km < ntile_mine; ++km) {
   f32x16 acc[16];
 #pragma unroll
   for (int xi = 0; xi < 16; ++xi)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+  for (km = 0; km < ntile_mine; ++km) {
   for (cm = 0; cm < nchunk; ++cm, ++c_next) {
     const int c = c_next;
     const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
@@ -430,6 +435,11 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);      // one accumulator row at a time: keeps the 256 accumulator reads from piling up
     }
+    // the accumulators of the next tile: 16 MFMAs with zero operands (0 * 0 + 0) instead of 256 v_accvgpr_write; they
+    // run in the matrix pipe while the stores below are issued
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) acc[xi] = mfma_zero();
+    __builtin_amdgcn_sched_barrier(0);
     {
       const int c4 = lane & 7;
       const int cbase = nb * WN + wn * 32 + c4 * 4;
