@@ -29,8 +29,9 @@ pick = {
     'conv_wino_wgrad/conv_2': ('wino_wgrad_kernel', 1),
     'routing_fwd': ('caps1_fwd_kernel<5, true>', -1),
     'routing_bwd': ('caps1_bwd_kernel<5, true>', -1),
-    'conv_wino2_fwd/conv_3': ('wino2_conv_kernel', -1),
-    'conv_wino2_wgrad/conv_3': ('wino2_wgrad_kernel', -1),
+    'conv_wino2_fwd/conv_3': ('wino2_conv_kernel<0, false>', -1),
+    'conv_wino2_dgrad/conv_3': ('wino2_conv_kernel<1, false>', -1),
+    'conv_wino2_wgrad/conv_3': ('wino2_wgrad_kernel<false>', -1),
     'conv_gemm_fwd/conv_3': ('conv_gemm_kernel<1, true>', -1),
     'conv_wgrad/conv_3': ('conv_wgrad_kernel<2, 1, 2, 2, true>', -1),
 }
