@@ -582,3 +582,90 @@ def test_detect_acc_device_matches_reference(tag):
     bad[0, 0, 0, 0], bad[0, 0, 0, 3] = 0.9, -0.2              # negative width: x1 > x2
     with pytest.raises(AssertionError):
         metrics.detect_confusion(y, bad, p)
+
+
+# ------------------------------------------------------------------------ full size (BASELINE configs[2]) properties
+def _dot64(a, b, chunk=1 << 26):
+    """sum(a * b) accumulated in float64, in chunks (the tensors are several GB)."""
+    a, b = a.reshape(-1), b.reshape(-1)
+    s = torch.zeros((), dtype=torch.float64, device=a.device)
+    for i in range(0, a.numel(), chunk):
+        s += torch.dot(a[i:i + chunk].double(), b[i:i + chunk].double())
+    return s.item()
+
+
+@pytest.mark.parametrize('layer', ['conv_2', 'conv_3'])
+def test_full_size_conv_sampled_outputs_and_adjoint_identities(layer):
+    """BASELINE configs[2] shapes (batch 32, 416x416): the oracle cannot run them in seconds, so the forward result is
+    checked on 256 sampled outputs against their exact fp64 dot products (incl. image corners and edges), and the two
+    gradients through the adjoint identities <conv(x), dz> = <x, dgrad(dz)> = <w, wgrad(x, dz)> over ALL elements."""
+    from capsyolo_amd import ops
+    B, H = 32, 416
+    Cin, Cout, k, s, p = (128, 256, 3, 1, 1) if layer == 'conv_2' else (256, 64, 4, 2, 1)
+    Ho = (H + 2 * p - k) // s + 1
+    g = torch.Generator(device='cuda').manual_seed(7 if layer == 'conv_2' else 8)
+    x = torch.randn((B, H, H, Cin), generator=g, device=dev())
+    w = torch.randn((Cout, Cin, k, k), generator=g, device=dev()) * (1.0 / (Cin * k * k)) ** 0.5
+    b = torch.randn((Cout,), generator=g, device=dev())
+    y = ops.conv_forward(x, w, b, k, s, p)
+    assert tuple(y.shape) == (B, Ho, Ho, Cout)
+    # ---- sampled outputs: corners, edges and random interior points
+    rs = np.random.RandomState(3)
+    pts = [(0, 0, 0, 0), (B - 1, Ho - 1, Ho - 1, Cout - 1), (1, 0, Ho - 1, 5), (2, Ho - 1, 0, 7), (3, 0, Ho // 2, 1),
+           (4, Ho // 2, Ho - 1, 2)]
+    pts += [(int(rs.randint(B)), int(rs.randint(Ho)), int(rs.randint(Ho)), int(rs.randint(Cout))) for _ in range(250)]
+    wd = w.double()
+    for (bi, oy, ox, co) in pts:
+        acc = b[co].double()
+        for kh in range(k):
+            iy = oy * s - p + kh
+            if iy < 0 or iy >= H:
+                continue
+            for kw in range(k):
+                ix = ox * s - p + kw
+                if ix < 0 or ix >= H:
+                    continue
+                acc = acc + torch.dot(x[bi, iy, ix].double(), wd[co, :, kh, kw])
+        got, ref = y[bi, oy, ox, co].item(), acc.item()
+        assert abs(got - ref) <= 2e-5 * max(1.0, abs(ref)), (layer, bi, oy, ox, co, got, ref)
+    # ---- adjoint identities (bias removed: <y - b, dz>)
+    dz = torch.randn((B, Ho, Ho, Cout), generator=g, device=dev())
+    y0 = ops.conv_forward(x, w, None, k, s, p)
+    lhs = _dot64(y0, dz)
+    del y, y0
+    dx = ops.conv_dgrad(dz, w, (B, H, H, Cin), k, s, p)
+    mid = _dot64(x, dx)
+    del dx
+    dw = ops.conv_wgrad(x, dz, k, s, p)
+    rhs = _dot64(w, dw)
+    scale = (_dot64(dz, dz) ** 0.5) * ((B * Ho * Ho * Cout) ** 0.5)      # ~ |y| |dz|
+    assert abs(lhs - mid) <= 1e-6 * scale and abs(lhs - rhs) <= 1e-6 * scale, (lhs, mid, rhs, scale)
+
+
+def test_full_size_routing_head_matches_fp64_and_gather_is_address_only():
+    """BASELINE configs[2] head: R = 13*13*32 = 5408 rows, N = 512, C = 1, 8 -> 5, 3 iterations.  With one output capsule
+    the coupling is identically 1, so v = squash(sum_i u_i W_i): checked in fp64 over all rows, with its gradients; the
+    cell gather folded into the loads must give exactly what the oracle's explicit gather + the plain kernel give."""
+    from capsyolo_amd import ops
+    from oracle.models import cell_gather
+    g, B, N, Din, Dout = 13, 32, 512, 8, 5
+    feat = rnd((B, 256, 4 * g, 4 * g), 51, 0.7)
+    W = rnd((1, N, 1, Din, Dout), 52, 0.1)
+    u = cell_gather(feat, g).contiguous()                                  # [g*g*B, 512, 8] on the CPU (oracle)
+    assert tuple(u.shape) == (g * g * B, N, Din)
+    ud, Wd = u.to(dev()).requires_grad_(True), W.to(dev()).requires_grad_(True)
+    v = ops.routing(ud, Wd, 3)
+    G = rnd(tuple(v.shape), 53).to(dev())
+    (v * G).sum().backward()
+    u64, W64 = u.to(dev()).double().requires_grad_(True), W.to(dev()).double().requires_grad_(True)
+    s = torch.einsum('rnd,ndo->ro', u64, W64[0, :, 0])
+    n2 = (s * s).sum(-1, keepdim=True)
+    vr = (n2 / (1 + n2)) * s / n2.sqrt()
+    (vr * G.double().reshape(vr.shape)).sum().backward()
+    close(v.reshape(vr.shape), vr, 2e-5, 1e-6)
+    close(ud.grad, u64.grad, 1e-4, 1e-5)
+    close(Wd.grad, W64.grad, 1e-4, 1e-5)
+    fh = feat.permute(0, 2, 3, 1).contiguous().to(dev())
+    vg = ops.routing(fh, W.to(dev()), 3, g, B)                             # [B, g, g, 1, 5]
+    vp = v.detach().reshape(g, g, B, 1, Dout).permute(2, 0, 1, 3, 4)
+    assert torch.equal(vg, vp.contiguous())
