@@ -54,6 +54,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=32, help='per-GPU batch (BASELINE configs[2]: 32)')
     ap.add_argument('--input', type=int, default=416, help='image side; n_grid = input/32')
     ap.add_argument('--n_iter', type=int, default=3)
+    ap.add_argument('--sync-bn', action='store_true', help='N>1: BatchNorm statistics over the global batch (2 small all-reduces per BN layer)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=2, help='sample batch for the CPU baseline')
     ap.add_argument('--cpu-steps', type=int, default=2)
@@ -127,6 +128,7 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    ops.SYNC_BN = bool(args.sync_bn) and world > 1
     g = args.input // 32
     B = args.batch
     p = types.SimpleNamespace(n_classes=43, n_grid=g, n_boxes=2, dropout=0.0, recon=False, recon_coef=5e-4,
@@ -236,7 +238,7 @@ def main():
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'experiments/darkcapsule GTSDB-shaped %dx%d, n_grid %d, %d routing iters, batch %d per GPU, '
                                    'recon off, fp32 (BASELINE configs[2])' % (args.input, args.input, g, args.n_iter, B),
-                       'global_batch': world * B, 'parallelism': 'dp%d' % world, 'final_loss': round(final_loss, 6)},
+                       'global_batch': world * B, 'parallelism': 'dp%d%s' % (world, '+syncbn' if (args.sync_bn and world > 1) else ''), 'final_loss': round(final_loss, 6)},
             'roofline': cands[0] if cands else None,
             'roofline_other_conv2': cands[1:],
             'roofline_routing': {'kernel': 'caps1_fwd_kernel<5,true> (fused routing, C=1, cell gather folded into the load; '

@@ -261,6 +261,17 @@ class ConvBlockCfg(object):
         self.slope = slope      # None: no activation; 0.0: ReLU; else LeakyReLU slope
 
 
+SYNC_BN = False     # data parallel only: BatchNorm statistics (forward sums, backward sums) summed over all ranks, so
+                    # that N ranks x batch B train exactly like one process on the global batch N*B
+
+
+def _sync_world():
+    import torch.distributed as dist
+    if SYNC_BN and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist, dist.get_world_size()
+    return None, 1
+
+
 class _ConvBlock(torch.autograd.Function):
     """conv -> [BatchNorm (batch statistics from the conv epilogue)] -> [Leaky]ReLU, saving only x and z."""
 
@@ -292,7 +303,10 @@ class _ConvBlock(torch.autograd.Function):
             stats = torch.zeros((STATS_COPIES, N, 2), dtype=torch.float64, device=x.device)
             z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name, ina)
             P = z.numel() // N
-            call('cy_bn_finalize', _ptr(stats), P, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
+            dist, world = _sync_world()
+            if dist is not None:              # sum z / sum z^2 over the global batch (equal shards: dp.shard_range)
+                dist.all_reduce(stats)
+            call('cy_bn_finalize', _ptr(stats), P * world, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean),
                  _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean),
                  _ptr(invstd), N, st)
             bn.num_batches_tracked += 1
@@ -346,6 +360,13 @@ class _ConvBlock(torch.autograd.Function):
                 red = _empty((N, 2), z, torch.float64)
                 call('cy_bn_bwd_reduce', _ptr(z), _ptr(da), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), slope,
                      _ptr(red), P, N, st)
+            dist, world = _sync_world()
+            if dist is not None:
+                # global sums / world: the apply kernel divides by the LOCAL pixel count, which then gives the global
+                # means; dgamma / dbeta come out as (global sum) / world, what the gradient all-reduce MEAN expects
+                red = red.contiguous()
+                dist.all_reduce(red)
+                red /= world
             dz = torch.empty_like(z)
             dgamma, dbeta = _empty((N,), z), _empty((N,), z)
             call('cy_bn_bwd_apply', _ptr(z), _ptr(da), _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),

@@ -200,6 +200,9 @@ def main(argv=None):
         model_dir = args.model_dir
     params = load_params(model_dir, args)
     params.rank, params.world, local_rank = dp.init_from_env()
+    if params.world > 1 and getattr(params, 'sync_bn', False):     # optional params.json key (new; data parallel only)
+        from capsyolo_amd import ops as _ops
+        _ops.SYNC_BN = True
     if params.device == 'cuda':
         torch.cuda.set_device(local_rank)
     np.random.seed(args.seed)
