@@ -803,6 +803,13 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     const int ggr = cg - ggb * ngroups;
     ggy = ggr / a.gw; ggx = ggr - ggy * a.gw;
   }
+  // as in the forward kernel the end-of-chunk barrier stands at slot WS_BAR (all LDS writes <= slot 44, all fragment
+  // fetches <= slot 49) and the next chunk's first two fragment sets are fetched under the last MFMAs
+  f32x4 fa_[4], fb_[4];
+  fa_[0] = *(const f32x4*)(Vs + fragA);
+  fb_[0] = *(const f32x4*)(Zs + fragB);
+  fa_[1] = *(const f32x4*)(Vs + fragA + 2 * SLAB);
+  fb_[1] = *(const f32x4*)(Zs + fragB + 2 * SLAB);
   for (int c = 0; c < nchunk; ++c) {
     const float* vb_ = Vs + (c & 1) * VU_BUF + fragA;
     const float* ub_ = Zs + (c & 1) * VU_BUF + fragB;
@@ -821,11 +828,8 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
     const bool gf_next = is_fast(ggy, ggx);
     const char* xb_ = xall + (gf_next ? ggb * ximgb + (size_t)(((ggy * 4 - 1) * a.W + ggx * 8 - 1) * a.Cin) * 4 : (size_t)0);
     const char* zb_ = zall + (gf_next ? ggb * zimgb + (size_t)((ggy * 4 * a.W + ggx * 8) * a.Cout) * 4 : (size_t)0);
-    f32x4 fa_[4], fb_[4];
-    fa_[0] = *(const f32x4*)(vb_);
-    fb_[0] = *(const f32x4*)(ub_);
-    fa_[1] = *(const f32x4*)(vb_ + 2 * SLAB);
-    fb_[1] = *(const f32x4*)(ub_ + 2 * SLAB);
+    const float* vn_ = Vs + ((c + 1) & 1) * VU_BUF + fragA;         // fragments of chunk c+1
+    const float* un_ = Zs + ((c + 1) & 1) * VU_BUF + fragB;
 #define WGSLOT(SIDX)                                                                                \
     {                                                                                               \
       constexpr int sidx = (SIDX);                                                                  \
@@ -863,6 +867,15 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
       } else if (kind == 7) {               /* chunk c+2: one float4 of registers -> raw LDS */    \
         if (k_ < 4) *(f32x4*)(Rw + (prow + 16 * (k_ & 3)) * 64 + c4 * 4) = gx[k_ & 3];              \
         else *(f32x4*)(Rw + (XPS + prow + 16 * (k_ & 1)) * 64 + c4 * 4) = gz[k_ & 1];               \
+      } else if (sidx == WS_BAR) {          /* end-of-chunk barrier */                             \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                                         \
+        __builtin_amdgcn_s_barrier();                                                               \
+      } else if (sidx == WS_BAR + 2) {      /* positions 12, 13 are done with sets 0 and 1 */      \
+        fa_[0] = *(const f32x4*)(vn_);                                                              \
+        fb_[0] = *(const f32x4*)(un_);                                                              \
+      } else if (sidx == WS_BAR + 3) {                                                              \
+        fa_[1] = *(const f32x4*)(vn_ + 2 * SLAB);                                                   \
+        fb_[1] = *(const f32x4*)(un_ + 2 * SLAB);                                                   \
       }                                                                                             \
       __builtin_amdgcn_sched_barrier(0);                                                            \
     }
@@ -887,9 +900,9 @@ __global__ __launch_bounds__(256, 1) void wino_wgrad_kernel(WinoWgradArgs a) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) Gz(q, ggb, ggy, ggx, false);
       }
+      __syncthreads();                      // the zeroed padding must be in LDS before any wave transforms the patch
     }
     gfast = gf_next;
-    __syncthreads();
   }
 
   // ---- per-image partial dU[xi][ci][co] -> slab[b]
