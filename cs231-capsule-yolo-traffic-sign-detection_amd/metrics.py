@@ -1,4 +1,5 @@
-"""Detection metric of the reference on the device: metrics.detect_acc (metrics.py:245-262).
+"""Detection metrics of the reference on the device: metrics.detect_acc / detect_and_recog_acc / detect_AP
+(metrics.py:193-282).
 
 The reference decodes both arrays to boxes with numpy and matches them with two nested Python loops per image
 (metrics.py:136-147) every `eval_every` epochs; here the decoding (`cy_yolo_decode_boxes`) and the IoU matching
@@ -43,9 +44,44 @@ def detect_acc(y, y_hat, params):
     return 2 * p * r / (p + r + 1e-8)
 
 
+def detect_and_recog_confusion(y, y_hat, params, conf_th=0.5, iou_th=0.5):
+    """(TP, FP, FN) of metrics.py:264-280: the reference loops over classes and images and matches the boxes of one
+    (image, class) pair at a time; here every pair is one block of the same kernel -- the boxes are sorted by the key
+    image * n_classes + class on the device, which makes each pair a contiguous range."""
+    C = int(params.n_classes)
+    if C <= 0:
+        raise ValueError('detect_and_recog_acc needs a classifying head (n_classes > 0)')
+    sets = []
+    for arr in (y, y_hat):
+        n, idx, xy, cls = utils.decode_boxes_device(arr, params, None, conf_th)
+        if n:
+            key, order = torch.sort(idx.long() * C + cls.long(), stable=True)
+            idx, xy = key.to(torch.int32).contiguous(), xy[order].contiguous()
+        sets.append((n, idx, xy, cls))
+    batch, g = int(y.shape[0]), int(y.shape[1])
+    nb_max = max((int(y.shape[3]) - C) // 5, (int(y_hat.shape[3]) - C) // 5)
+    (n1, gi, gxy, _), (n2, pi, pxy, _) = sets
+    out = torch.zeros(4, dtype=torch.int32, device='cuda')
+    call('cy_detect_confusion', gi.data_ptr() if n1 else None, gxy.data_ptr() if n1 else None, n1,
+         pi.data_ptr() if n2 else None, pxy.data_ptr() if n2 else None, n2, batch * C, float(iou_th), g * g * nb_max,
+         out.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    tp, fp, fn, bad = [int(v) for v in out.cpu().numpy()]
+    if bad:
+        raise AssertionError('malformed box (x1 > x2 or y1 > y2) in %d case(s)' % bad)
+    return tp, fp, fn
+
+
+def detect_and_recog_acc(y, y_hat, params, show=False, save=False):
+    """metrics.py:264-282: F1 of detection + recognition; the registry's metric of darknet_r and darkcapsule
+    (main.py:262-264)."""
+    p, r = precision_and_recall(*detect_and_recog_confusion(y, y_hat, params))
+    return 2 * p * r / (p + r + 1e-8)
+
+
 def recog_acc(y, y_hat, params):
     """metrics.py:9-11."""
-    return np.sum(np.asarray(y) == np.argmax(np.asarray(y_hat), axis=1)) / len(y)
+    y, y_hat = [t.detach().cpu().numpy() if torch.is_tensor(t) else np.asarray(t) for t in (y, y_hat)]
+    return np.sum(y == np.argmax(y_hat, axis=1)) / len(y)
 
 
 def average_precision(p, r):

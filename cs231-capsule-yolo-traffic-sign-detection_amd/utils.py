@@ -82,6 +82,8 @@ def decode_boxes_device(y, params, image_hw=None, conf_th=0.5):
     batch, g, _, D = yt.shape
     C = int(params.n_classes)
     nb = int((D - C) / 5)
+    if nb < 1:          # e.g. DarkCapsuleNet's [B,g,g,5] output with n_classes = 43: the reference's reshape fails here too
+        raise ValueError('y has %d values per cell: no box left after %d class scores (utils.py:291-293)' % (D, C))
     cap = batch * g * g * nb
     dev = yt.device
     count = torch.zeros(1, dtype=torch.int32, device=dev)

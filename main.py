@@ -10,8 +10,8 @@ keys, same registry shape ``name -> (ModelCls, loss_fn, predict_fn, metric)`` (m
   params.json key ``n_iter`` (routing iterations, default 3)
 Data-parallel: launch with ``python -m torch.distributed.run --nproc-per-node N main.py ...``; every rank takes
 its shard of each global batch and gradients are averaged with one RCCL all-reduce per step.
-Metrics (metrics.py), tensorboardX and torchsummary are outside the hot path; the metric slot of the registry is
-kept and ``--no_metric`` behaviour is the default when no metric implementation is registered.
+tensorboardX and torchsummary are outside the hot path; the registry's metrics (main.py:259-264) run through
+capsyolo_amd.metrics (detection metrics on the device), ``--no_metric`` skips them like the reference.
 """
 import argparse
 import os
@@ -53,11 +53,11 @@ parser.add_argument('--synthetic', type=int, default=0, help='use N synthetic sa
 parser.add_argument('--n_epochs', type=int, default=0, help='override params.json n_epochs')
 
 model_loss_predict = {
-    'cnn': (ConvNet, cnn_loss, class_pred, None),
-    'capsule': (CapsuleNet, capsule_loss, class_pred, None),
+    'cnn': (ConvNet, cnn_loss, class_pred, metrics.recog_acc),                    # main.py:259-260
+    'capsule': (CapsuleNet, capsule_loss, class_pred, metrics.recog_acc),
     'darknet_d': (DarkNet, dark_loss, dark_forward, metrics.detect_acc),          # main.py:261; on the device here
-    'darknet_r': (DarkNet, dark_loss, dark_forward, None),
-    'darkcapsule': (DarkCapsuleNet, darkcapsule_loss, None, None),
+    'darknet_r': (DarkNet, dark_loss, dark_forward, metrics.detect_and_recog_acc),        # main.py:262
+    'darkcapsule': (DarkCapsuleNet, darkcapsule_loss, None, metrics.detect_and_recog_acc),   # main.py:264 (the later key wins)
 }
 
 
@@ -121,7 +121,11 @@ def evaluate(x, y, model, loss_fn, metric, params):
     score = -1
     if metric is not None and y_hat:
         cap = getattr(config, 'max_metric_samples', 1000)
-        score = float(metric(torch.cat(y_true)[:cap], torch.cat(y_hat)[:cap], params))
+        try:
+            score = float(metric(torch.cat(y_true)[:cap], torch.cat(y_hat)[:cap], params))
+        except ValueError as e:     # e.g. darkcapsule's [B,g,g,5] output has no class scores for its registry metric
+            if params.rank == 0:    # (the reference stops here, metrics.py:267-268; pass --no_metric to skip the attempt)
+                print('metric not computed: %s' % e)
     return avg_loss, score
 
 
@@ -213,6 +217,8 @@ def main(argv=None):
         raise SystemExit('model %s runs on hand-written gfx950 kernels only; no GPU is visible' % args.model)
 
     model_cls, loss_fn, predict_fn, metric = model_loss_predict[args.model]
+    if args.no_metric:                                                                 # main.py:87,133
+        metric = None
     model = model_cls(params).to(device=params.device)
     dp.broadcast_parameters(model)
     if args.fine_tune > 0:

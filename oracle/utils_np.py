@@ -106,3 +106,23 @@ def detect_AP(y, y_hat, darknet_input):
             rs.append(tp / (tp + fn) if tp + fn else 0.0)
         aps.append(average_precision(np.array(ps), np.array(rs)))
     return np.mean(np.array(aps))
+
+
+def detect_and_recog_confusion(y, y_hat, n_classes, darknet_input, conf_th=0.5, iou_th=0.5):
+    """TP, FP, FN of metrics.py:264-280: boxes are matched per image AND per class."""
+    yi, yb, yc = y_to_boxes_vec(y, n_classes, darknet_input, conf_th=conf_th)
+    hi, hb, hc = y_to_boxes_vec(y_hat, n_classes, darknet_input, conf_th=conf_th)
+    tot = np.zeros(3, dtype=np.int64)
+    for c in range(n_classes):
+        for j in range(y.shape[0]):
+            tot += np.array(single_img_confusion(yb[(yi == j) * (yc == c)], hb[(hi == j) * (hc == c)], iou_th))
+    return tot
+
+
+def detect_and_recog_acc(y, y_hat, n_classes, darknet_input):
+    """metrics.py:264-282: F1 of detection + recognition (the registry's metric of darknet_r and darkcapsule, main.py:262-264)."""
+    tp, fp, fn = [int(v) for v in detect_and_recog_confusion(y, y_hat, n_classes, darknet_input)]
+    p = tp / (tp + fp) if tp + fp else 0.0
+    r = tp / (tp + fn) if tp + fn else 0.0
+    return 2 * p * r / (p + r + 1e-8)
+

@@ -584,6 +584,23 @@ def test_detect_acc_device_matches_reference(tag):
         metrics.detect_confusion(y, bad, p)
 
 
+@pytest.mark.parametrize('tag', ['ra', 'rb'])
+def test_detect_and_recog_acc_device_matches_reference(tag):
+    """Per-(image, class) matching on the device against the reference's metrics.detect_and_recog_acc (metrics.py:264-282)
+    and the numpy oracle's TP / FP / FN."""
+    import types
+    from capsyolo_amd import metrics
+    from helpers import load_golden
+    from oracle import utils_np
+    from test_oracle_golden import _detect_recog_case
+    gold = load_golden('metrics')
+    seed, B, g, nb, C = [int(v) for v in gold[tag + '_cfg']]
+    y, y_hat = _detect_recog_case(seed, B, g, nb, C)
+    p = types.SimpleNamespace(n_classes=C, darknet_input=416)
+    assert list(metrics.detect_and_recog_confusion(y, y_hat, p)) == [int(v) for v in utils_np.detect_and_recog_confusion(y, y_hat, C, 416)]
+    assert abs(metrics.detect_and_recog_acc(y, y_hat, p) - float(gold[tag + '_f1'])) < 1e-15
+
+
 # ------------------------------------------------------------------------ full size (BASELINE configs[2]) properties
 def _dot64(a, b, chunk=1 << 26):
     """sum(a * b) accumulated in float64, in chunks (the tensors are several GB)."""

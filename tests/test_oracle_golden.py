@@ -309,3 +309,26 @@ def test_detect_acc_oracle_matches_reference(tag):
     assert utils_np.detect_acc(y, y_hat, 416) == float(gold[tag + '_f1'])
     if tag == 'c':
         assert utils_np.detect_AP(y, y_hat, 416) == float(gold[tag + '_ap'])
+
+
+def _detect_recog_case(seed, B, g, nb, C):
+    """tests/golden/make_golden.py:detect_recog_case (the inputs of the golden detect_and_recog_acc values)."""
+    rng = np.random.default_rng(seed + 1000)
+    y5, h5 = _detect_case(seed, B, g, nb)
+    cls = rng.integers(0, C, (B, g, g))
+    yc = np.eye(C)[cls] * y5[..., 0:1]
+    flip = rng.random((B, g, g)) < 0.2
+    hcls = np.where(flip, rng.integers(0, C, (B, g, g)), cls)
+    hc = (0.1 * rng.random((B, g, g, C)) + 0.8 * np.eye(C)[hcls]).astype(np.float32)
+    return np.concatenate([y5, yc], 3), np.concatenate([h5, hc], 3).astype(np.float32)
+
+
+@pytest.mark.parametrize('tag', ['ra', 'rb'])
+def test_detect_and_recog_acc_oracle_matches_reference(tag):
+    """oracle/utils_np.detect_and_recog_acc against the reference's metrics.detect_and_recog_acc (metrics.py:264-282)."""
+    from oracle import utils_np
+    gold = load_golden('metrics')
+    seed, B, g, nb, C = [int(v) for v in gold[tag + '_cfg']]
+    y, y_hat = _detect_recog_case(seed, B, g, nb, C)
+    assert utils_np.detect_and_recog_acc(y, y_hat, C, 416) == float(gold[tag + '_f1'])
+
