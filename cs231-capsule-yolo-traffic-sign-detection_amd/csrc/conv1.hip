@@ -1,0 +1,143 @@
+// First layer of the backbones (models.py:347-349 DarkCapsuleNet conv_1: 3 -> 128, models.py:132-136 DarkNet conv_1:
+// 3 -> 32; 3x3, stride 1, pad 1, NCHW image in): 1 % of the model's FLOPs but 2.8 GB of output at the headline shape,
+// i.e. a STORE-bound layer.  The implicit-GEMM kernel spends its time in block prologues (43 k blocks with one K tile
+// each, two per CU); here every wave is persistent and needs neither LDS nor barriers:
+//   * a wave owns tiles of 32 consecutive pixels of one image row x all output channels (NT = Cout / 32 MFMA tiles),
+//   * K = 27 taps -> 14 steps of mfma_f32_32x32x2f32; the B operand (weights, 14 NT registers) stays in registers for
+//     the whole launch, the A operand is read straight from the image (22 MB, L2-resident): lane (pixel i, k half) needs
+//     x[c][y + kh - 1][x0 + i + kw - 1], 128 contiguous bytes per (tap, half) -- fetched one tile ahead,
+//   * the accumulator layout (lane = channel, 16 pixel rows) stores 128 contiguous bytes per pixel: plain dword stores,
+//     full cache lines, no transposition,
+//   * BatchNorm statistics are kept per lane over ALL tiles of the wave: one pair of double atomics per channel and wave.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Conv1Args {
+  const float* X; const float* W; const float* bias; float* Y; double* stats;
+  int B, H, Wd, Cout;
+  long long ntiles;                         // B * H * Wd / 32
+};
+
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  const int segs = a.Wd / 32;
+  const size_t plane = (size_t)a.H * a.Wd;
+
+  // ---- per-lane tap geometry: step s uses k = 2 s + lh -> (c, kh, kw); k = 27 (s = 13, upper half) is padding
+  int toff[14];                             // offset of the tap from the pixel, in floats, inside the image
+  int tky[14], tkx[14];
+  float wreg[NT][14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + lh;
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, kh = (kk % 9) / 3, kw = kk % 3;
+    tky[s] = k < 27 ? kh - 1 : (1 << 20);   // padding step: never inside the image -> operand 0
+    tkx[s] = kw - 1;
+    toff[s] = (int)(c * plane) + (kh - 1) * a.Wd + (kw - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[nt][s] = k < 27 ? a.W[((size_t)(nt * 32 + li) * 3 + c) * 9 + kh * 3 + kw] : 0.f;
+  }
+  float bv[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = a.bias != nullptr ? a.bias[nt * 32 + li] : 0.f;
+  float ssum[NT], ssq[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+
+  auto load_a = [&](long long tile, float (&av)[14]) {
+    const int seg = (int)(tile % segs);
+    const long long row = tile / segs;
+    const int y = (int)(row % a.H), b = (int)(row / a.H);
+    const int x = seg * 32 + li;
+    const float* px = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + x;
+    const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;    // uniform
+    if (inner) {
+#pragma unroll
+      for (int s = 0; s < 14; ++s) av[s] = (s < 13 || lh == 0) ? px[toff[s]] : 0.f;
+    } else {
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        const bool ok = (unsigned)(y + tky[s]) < (unsigned)a.H && (unsigned)(x + tkx[s]) < (unsigned)a.Wd;
+        const float v = px[ok ? toff[s] : 0];
+        av[s] = ok ? v : 0.f;
+      }
+    }
+  };
+
+  float acur[14], anext[14];
+  long long tile = gw;
+  if (tile < a.ntiles) load_a(tile, acur);
+  for (; tile < a.ntiles; tile += nw) {
+    const long long tn = tile + nw;
+    if (tn < a.ntiles) load_a(tn, anext);   // one tile of latency cover
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 14; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[s], wreg[nt][s], acc[nt], 0, 0, 0);
+    // ---- epilogue: + bias, statistics, 128 contiguous bytes per pixel and MFMA tile
+    float* yp = a.Y + (size_t)tile * 32 * a.Cout + li;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const float v = acc[nt][r] + bv[nt];
+        ssum[nt] += v;
+        ssq[nt] = __builtin_fmaf(v, v, ssq[nt]);
+        yp[(size_t)p * a.Cout + nt * 32] = v;
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 14; ++s) acur[s] = anext[s];
+  }
+  if (a.stats != nullptr) {
+    double* st = a.stats + (size_t)((blockIdx.x * 4 + wave) % CY_STATS_COPIES) * a.Cout * 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float s1 = ssum[nt] + __shfl_xor(ssum[nt], 32, 64), s2 = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
+      if (lh == 0) {
+        atomicAdd(st + 2 * (nt * 32 + li), (double)s1);
+        atomicAdd(st + 2 * (nt * 32 + li) + 1, (double)s2);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int H,
+                                int Wd, int Cout, void* stream) {
+  CY_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0, "cy_conv1_3x3_fwd: bad arguments");
+  CY_REQUIRE(Wd % 32 == 0, "cy_conv1_3x3_fwd: W=%d must be a multiple of 32", Wd);
+  CY_REQUIRE(Cout == 32 || Cout == 64 || Cout == 128, "cy_conv1_3x3_fwd: Cout=%d must be 32, 64 or 128", Cout);
+  CY_REQUIRE((long long)3 * H * Wd < (1ll << 30), "cy_conv1_3x3_fwd: image too large for 32-bit offsets");
+  Conv1Args a;
+  a.X = X; a.W = W; a.bias = bias; a.Y = Y; a.stats = stats;
+  a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout;
+  a.ntiles = (long long)B * H * (Wd / 32);
+  int dev = 0, ncu = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "cy_conv1_3x3_fwd: cannot query the CU count: %s", hipGetErrorString(he));
+  long long blocks = (a.ntiles + 3) / 4;
+  if (blocks > ncu) blocks = ncu;           // persistent: one wave per SIMD
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout == 128) conv1_fwd_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else if (Cout == 64) conv1_fwd_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else conv1_fwd_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(a);
+  CY_LAUNCH_CHECK("cy_conv1_3x3_fwd");
+  return 0;
+}

@@ -79,6 +79,7 @@ def _x_geometry(x, nchw):
 
 
 STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
+USE_CONV1 = True         # 3 -> {32, 64, 128} channels, 3x3, NCHW image (the backbones' first layer): dedicated store-bound kernels
 USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short reductions; kept switchable)
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
@@ -135,6 +136,14 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
             call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
                  float(isl), B, Hi, Wi, Cin, Cout, st)
         return y
+    if (USE_CONV1 and nchw and k == 3 and stride == 1 and pad == 1 and Cin == 3 and Cout in (32, 64, 128) and Wi % 32 == 0
+            and not relu and x.is_contiguous()):
+        # the backbones' first layer (store-bound): persistent waves, operands from registers / L2
+        st = _stream()
+        z = _empty((B, Ho, Wo, Cout), x)
+        with timer.range('conv1_fwd/' + tag):
+            call('cy_conv1_3x3_fwd', _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(z), _ptr(stats), B, Hi, Wi, Cout, st)
+        return z
     st = _stream()
     wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
     call('cy_conv_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, k, k, 0, 0, 1, 0, st)

@@ -57,6 +57,13 @@ typedef struct {
   float bn_slope;
 } cy_conv_gemm_t;
 
+/* First layer of the backbones (models.py:347-349 DarkCapsuleNet conv_1 3 -> 128, models.py:132-136 DarkNet conv_1
+ * 3 -> 32): 3x3 / stride 1 / pad 1 on the NCHW image X[B][3][H][W] (W % 32 == 0) with PyTorch-layout weights
+ * W[Cout][3][3][3], Cout in {32, 64, 128}; Y[B][H][W][Cout] NHWC.  bias / stats as in cy_conv_gemm (either may be NULL).
+ * A store-bound layer: persistent waves, operands from registers / L2, no LDS. */
+int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int H, int Wd,
+                     int Cout, void* stream);
+
 /* number of floats of a packed-weight buffer for (K = TH*TW*Cin, N) */
 long long cy_conv_packed_floats(int K, int N);
 /* pack PyTorch-layout weights W[Cout][Cin][KH][KW] for the forward GEMM of a (sub)set of taps:

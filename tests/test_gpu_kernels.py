@@ -601,6 +601,36 @@ def test_detect_and_recog_acc_device_matches_reference(tag):
     assert abs(metrics.detect_and_recog_acc(y, y_hat, p) - float(gold[tag + '_f1'])) < 1e-15
 
 
+@pytest.mark.parametrize('case', [(2, 32, 32, 128), (3, 64, 96, 32), (1, 5, 32, 64), (2, 33, 64, 128)])
+def test_first_layer_kernel_matches_direct_and_fp64(case):
+    """cy_conv1_3x3_fwd (3 input channels, NCHW image, persistent waves) against torch fp64 and the implicit-GEMM kernel,
+    incl. bias and BatchNorm statistics, image borders, one-segment rows."""
+    from capsyolo_amd import ops
+    B, H, W, Cout = case
+    x = rnd((B, 3, H, W), 131)
+    w = rnd((Cout, 3, 3, 3), 132, 0.2)
+    b = rnd((Cout,), 133)
+    zr = F.conv2d(x.double(), w.double(), b.double(), stride=1, padding=1)
+    st = torch.zeros((ops.STATS_COPIES, Cout, 2), dtype=torch.float64, device=dev())
+    ops.timer.reset(); ops.timer.enabled = True
+    try:
+        z = ops.conv_forward(x.to(dev()), w.to(dev()), b.to(dev()), 3, 1, 1, True, st, False, 'c1')
+        torch.cuda.synchronize()
+        assert any(k.startswith('conv1_fwd/') for k in ops.timer.summary())
+    finally:
+        ops.timer.enabled = False
+    close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
+    s = st.sum(0).cpu()
+    close(s[:, 0], zr.sum((0, 2, 3)), 1e-5, 1e-5)
+    close(s[:, 1], (zr * zr).sum((0, 2, 3)), 1e-5, 1e-5)
+    ops.USE_CONV1 = False
+    try:
+        z0 = ops.conv_forward(x.to(dev()), w.to(dev()), b.to(dev()), 3, 1, 1, True, None, False, 'c1')
+    finally:
+        ops.USE_CONV1 = True
+    close(z, z0, 1e-5, 1e-5)
+
+
 # ------------------------------------------------------------------------ full size (BASELINE configs[2]) properties
 def _dot64(a, b, chunk=1 << 26):
     """sum(a * b) accumulated in float64, in chunks (the tensors are several GB)."""
