@@ -56,6 +56,7 @@ _SIGS = {
     'cy_channel_sum': [_P, _P, _L, _I, _P],
     'cy_wino_pack_weights': [_P, _P, _I, _I, _I, _P],
     'cy_conv1_3x3_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'cy_conv1_3x3_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_wino2_pack_weights': [_P, _P, _I, _I, _P],
@@ -100,6 +101,7 @@ _RET = {
     'capsyolo_abi_version': (C.c_int, []),
     'cy_conv_packed_floats': (_L, [_I, _I]),
     'cy_wino_packed_floats': (_L, [_I, _I]),
+    'cy_conv1_3x3_wgrad_ws_floats': (_L, [_I, _I, _I, _I]),
     'cy_wino2_packed_floats': (_L, [_I, _I]),
     'cy_wino2_dgrad_packed_floats': (_L, [_I, _I]),
     'cy_wino2_wgrad_ws_floats': (_L, [_I, _I, _I]),

@@ -116,7 +116,131 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
   }
 }
 
+// ---- weight gradient of the same layer: dW[co][c][kh][kw] = sum over pixels of dZ[pixel][co] * x[c][y + kh - 1][x + kw - 1].
+// The pixels are the MFMA k dimension: D[co (32 NT rows)][tap (27 of 32 columns)] += A[co][pixel] B[pixel][tap] with
+// A = dZ (lane = channel, k half = pixel parity: 128 contiguous bytes per pixel) and B = the image patch (lane = tap:
+// every lane walks ITS OWN row of the image, consecutive pixels = consecutive addresses).  Columns 27..31 accumulate
+// finite garbage and are never stored.  Every wave is persistent over tiles of 32 pixels (16 MFMA steps x NT), loads
+// one tile ahead, and leaves its partial sums in a slab; `conv1_wgrad_finish_kernel` adds the slabs in a fixed order.
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv1_wgrad_kernel(Conv1Args a, float* __restrict__ slabs) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  const int segs = a.Wd / 32;
+  const size_t plane = (size_t)a.H * a.Wd;
+  const int kk = li < 27 ? li : 0;          // this lane's tap (columns 27..31 read tap 0's data: never stored)
+  const int tc = kk / 9, tkh = (kk % 9) / 3, tkw = kk % 3;
+  const int toff = (int)(tc * plane) + (tkh - 1) * a.Wd + (tkw - 1) + lh;    // + 2 s: pixel 2 s + lh of the tile
+
+  auto load_tile = [&](long long tile, float (&av)[NT][16], float (&bv)[16]) {
+    const int seg = (int)(tile % segs);
+    const long long row = tile / segs;
+    const int y = (int)(row % a.H), b = (int)(row / a.H);
+    const float* pz = a.Y + (size_t)tile * 32 * a.Cout + (size_t)lh * a.Cout + li;       // a.Y = dZ here
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) av[nt][s] = pz[(size_t)(2 * s) * a.Cout + nt * 32];
+    const float* px = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + seg * 32;
+    const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;              // uniform
+    if (inner) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bv[s] = px[toff + 2 * s];
+    } else {
+      const bool rowok = (unsigned)(y + tkh - 1) < (unsigned)a.H;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const bool ok = rowok && (unsigned)(seg * 32 + 2 * s + lh + tkw - 1) < (unsigned)a.Wd;
+        const float v = px[ok ? toff + 2 * s : 0];
+        bv[s] = ok ? v : 0.f;
+      }
+    }
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+  float acur[NT][16], bcur[16], anext[NT][16], bnext[16];
+  long long tile = gw;
+  if (tile < a.ntiles) load_tile(tile, acur, bcur);
+  for (; tile < a.ntiles; tile += nw) {
+    const long long tn = tile + nw;
+    if (tn < a.ntiles) load_tile(tn, anext, bnext);
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[nt][s], bcur[s], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      bcur[s] = bnext[s];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acur[nt][s] = anext[nt][s];
+    }
+  }
+  // slab[wave][co][32 taps]: lane li = tap (contiguous), accumulator row = channel
+  float* out = slabs + (size_t)gw * a.Cout * 32;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      out[(size_t)co * 32 + li] = acc[nt][r];
+    }
+}
+
+// dW[co][c][kh][kw] (= [co][27]) = sum over the waves' slabs, in slab order
+__global__ void conv1_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int nslab, int Cout) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= Cout * 27) return;
+  const int co = idx / 27, k = idx - co * 27;
+  float s = 0.f;
+  for (int w = 0; w < nslab; ++w) s += slabs[((size_t)w * Cout + co) * 32 + k];
+  dW[idx] = s;
+}
+
+static int conv1_blocks(long long ntiles, long long* blocks, const char* who) {
+  int dev = 0, ncu = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "%s: cannot query the CU count: %s", who, hipGetErrorString(he));
+  *blocks = (ntiles + 3) / 4;
+  if (*blocks > ncu) *blocks = ncu;         // persistent: one wave per SIMD
+  return 0;
+}
+
 }  // namespace
+
+extern "C" long long cy_conv1_3x3_wgrad_ws_floats(int B, int H, int Wd, int Cout) {
+  long long blocks = 0;
+  if (B <= 0 || H <= 0 || Wd <= 0 || Wd % 32 || conv1_blocks((long long)B * H * (Wd / 32), &blocks, "cy_conv1_3x3_wgrad_ws_floats")) return -1;
+  return blocks * 4 * Cout * 32;
+}
+
+extern "C" int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int Wd, int Cout,
+                                  void* stream) {
+  CY_REQUIRE(X && dZ && dW && ws && B > 0 && H > 0 && Wd > 0, "cy_conv1_3x3_wgrad: bad arguments");
+  CY_REQUIRE(Wd % 32 == 0, "cy_conv1_3x3_wgrad: W=%d must be a multiple of 32", Wd);
+  CY_REQUIRE(Cout == 32 || Cout == 64 || Cout == 128, "cy_conv1_3x3_wgrad: Cout=%d must be 32, 64 or 128", Cout);
+  CY_REQUIRE((long long)3 * H * Wd < (1ll << 30), "cy_conv1_3x3_wgrad: image too large for 32-bit offsets");
+  Conv1Args a;
+  a.X = X; a.W = nullptr; a.bias = nullptr; a.Y = const_cast<float*>(dZ); a.stats = nullptr;
+  a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout;
+  a.ntiles = (long long)B * H * (Wd / 32);
+  long long blocks = 0;
+  int rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_3x3_wgrad");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout == 128) conv1_wgrad_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(a, ws);
+  else if (Cout == 64) conv1_wgrad_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a, ws);
+  else conv1_wgrad_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(a, ws);
+  CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad");
+  conv1_wgrad_finish_kernel<<<(Cout * 27 + 255) / 256, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
+  CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad (finish)");
+  return 0;
+}
 
 extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int H,
                                 int Wd, int Cout, void* stream) {
@@ -128,12 +252,9 @@ extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bia
   a.X = X; a.W = W; a.bias = bias; a.Y = Y; a.stats = stats;
   a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout;
   a.ntiles = (long long)B * H * (Wd / 32);
-  int dev = 0, ncu = 0;
-  hipError_t he = hipGetDevice(&dev);
-  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "cy_conv1_3x3_fwd: cannot query the CU count: %s", hipGetErrorString(he));
-  long long blocks = (a.ntiles + 3) / 4;
-  if (blocks > ncu) blocks = ncu;           // persistent: one wave per SIMD
+  long long blocks = 0;
+  int rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_3x3_fwd");
+  if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (Cout == 128) conv1_fwd_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(a);
   else if (Cout == 64) conv1_fwd_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a);

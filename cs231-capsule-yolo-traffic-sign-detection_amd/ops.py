@@ -246,6 +246,12 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv', in_affine=None):
             call('cy_conv4x4s2_winograd_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), _ptr(isc), _ptr(ish), float(isl),
                  B, Hi, Wi, Cin, Cout, st)
         return dW
+    if (USE_CONV1 and nchw and k == 3 and stride == 1 and pad == 1 and Cin == 3 and Cout in (32, 64, 128) and Wi % 32 == 0
+            and in_affine is None and x.is_contiguous() and dz.is_contiguous()):
+        ws = _empty((query('cy_conv1_3x3_wgrad_ws_floats', B, Hi, Wi, Cout),), dz)
+        with timer.range('conv1_wgrad/' + tag):
+            call('cy_conv1_3x3_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cout, st)
+        return dW
     if in_affine is not None:
         raise _lib.HipExtensionError('a fused input affine needs the 4x4/stride-2 Winograd weight-gradient kernel')
     a = ConvWgrad(X=x.data_ptr(), dZ=dz.data_ptr(), dW=dW.data_ptr(), slabs=None,

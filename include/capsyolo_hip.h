@@ -63,6 +63,11 @@ typedef struct {
  * A store-bound layer: persistent waves, operands from registers / L2, no LDS. */
 int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int H, int Wd,
                      int Cout, void* stream);
+/* ... and its weight gradient dW[Cout][3][3][3] from X and dZ[B][H][W][Cout] (the weight-gradient half of nn.Conv2d
+ * backward for that layer); ws: cy_conv1_3x3_wgrad_ws_floats floats (one partial slab per persistent wave, added up in a
+ * fixed order: deterministic). */
+long long cy_conv1_3x3_wgrad_ws_floats(int B, int H, int Wd, int Cout);
+int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int Wd, int Cout, void* stream);
 
 /* number of floats of a packed-weight buffer for (K = TH*TW*Cin, N) */
 long long cy_conv_packed_floats(int K, int N);

@@ -629,6 +629,25 @@ def test_first_layer_kernel_matches_direct_and_fp64(case):
     finally:
         ops.USE_CONV1 = True
     close(z, z0, 1e-5, 1e-5)
+    # weight gradient (cy_conv1_3x3_wgrad: pixels are the MFMA k dimension, per-wave slabs)
+    xd, wd = x.double(), w.double().requires_grad_(True)
+    gz = rnd(tuple(zr.shape), 134)
+    F.conv2d(xd, wd, None, stride=1, padding=1).backward(gz.double())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    ops.timer.reset(); ops.timer.enabled = True
+    try:
+        dw = ops.conv_wgrad(x.to(dev()), gzd, 3, 1, 1, True, 'c1')
+        torch.cuda.synchronize()
+        assert any(k.startswith('conv1_wgrad/') for k in ops.timer.summary())
+    finally:
+        ops.timer.enabled = False
+    close(dw, wd.grad, 2e-5, 2e-5)
+    ops.USE_CONV1 = False
+    try:
+        dw0 = ops.conv_wgrad(x.to(dev()), gzd, 3, 1, 1, True, 'c1')
+    finally:
+        ops.USE_CONV1 = True
+    close(dw, dw0, 2e-5, 2e-5)
 
 
 # ------------------------------------------------------------------------ full size (BASELINE configs[2]) properties
