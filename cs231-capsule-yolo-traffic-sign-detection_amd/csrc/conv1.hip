@@ -137,11 +137,19 @@ __global__ __launch_bounds__(256, 1) void conv1_wgrad_kernel(Conv1Args a, float*
     const int seg = (int)(tile % segs);
     const long long row = tile / segs;
     const int y = (int)(row % a.H), b = (int)(row / a.H);
-    const float* pz = a.Y + (size_t)tile * 32 * a.Cout + (size_t)lh * a.Cout + li;       // a.Y = dZ here
+    // MFMA tile nt holds the channels NT * row + nt: a lane's NT operands of one pixel are NT consecutive floats
+    const float* pz = a.Y + (size_t)tile * 32 * a.Cout + (size_t)lh * a.Cout + NT * li;  // a.Y = dZ here
 #pragma unroll
-    for (int s = 0; s < 16; ++s)
+    for (int s = 0; s < 16; ++s) {
+      typedef float vecn __attribute__((ext_vector_type(NT)));
+      if constexpr (NT == 1) {
+        av[0][s] = pz[(size_t)(2 * s) * a.Cout];
+      } else {
+        const vecn v = *(const vecn*)(pz + (size_t)(2 * s) * a.Cout);
 #pragma unroll
-      for (int nt = 0; nt < NT; ++nt) av[nt][s] = pz[(size_t)(2 * s) * a.Cout + nt * 32];
+        for (int nt = 0; nt < NT; ++nt) av[nt][s] = v[nt];
+      }
+    }
     const float* px = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + seg * 32;
     const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;              // uniform
     if (inner) {
@@ -186,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void conv1_wgrad_kernel(Conv1Args a, float*
   for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int co = nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int co = NT * ((r & 3) + 8 * (r >> 2) + 4 * lh) + nt;
       out[(size_t)co * 32 + li] = acc[nt][r];
     }
 }
