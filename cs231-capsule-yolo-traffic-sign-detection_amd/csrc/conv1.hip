@@ -6,7 +6,8 @@
 //   * K = 27 taps -> 14 steps of mfma_f32_32x32x2f32; the B operand (weights, 14 NT registers) stays in registers for
 //     the whole launch, the A operand is read straight from the image (22 MB, L2-resident): lane (pixel i, k half) needs
 //     x[c][y + kh - 1][x0 + i + kw - 1], 128 contiguous bytes per (tap, half) -- fetched one tile ahead,
-//   * the accumulator layout (lane = channel, 16 pixel rows) stores 128 contiguous bytes per pixel: plain dword stores,
+//   * MFMA tile nt holds the channels NT * column + nt: in the accumulator layout (lane = column, 16 pixel rows) a lane
+//     owns NT consecutive channels of a pixel -- one 16-byte store per pixel and lane, 512 contiguous bytes per pixel,
 //     full cache lines, no transposition,
 //   * BatchNorm statistics are kept per lane over ALL tiles of the wave: one pair of double atomics per channel and wave.
 #include "common.h"
@@ -43,11 +44,11 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
     toff[s] = (int)(c * plane) + (kh - 1) * a.Wd + (kw - 1);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
-      wreg[nt][s] = k < 27 ? a.W[((size_t)(nt * 32 + li) * 3 + c) * 9 + kh * 3 + kw] : 0.f;
+      wreg[nt][s] = k < 27 ? a.W[((size_t)(NT * li + nt) * 3 + c) * 9 + kh * 3 + kw] : 0.f;
   }
   float bv[NT];
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt) bv[nt] = a.bias != nullptr ? a.bias[nt * 32 + li] : 0.f;
+  for (int nt = 0; nt < NT; ++nt) bv[nt] = a.bias != nullptr ? a.bias[NT * li + nt] : 0.f;
   float ssum[NT], ssq[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
@@ -87,17 +88,27 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
     for (int s = 0; s < 14; ++s)
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[s], wreg[nt][s], acc[nt], 0, 0, 0);
-    // ---- epilogue: + bias, statistics, 128 contiguous bytes per pixel and MFMA tile
-    float* yp = a.Y + (size_t)tile * 32 * a.Cout + li;
+    // ---- epilogue: + bias, statistics; MFMA tile nt holds the channels NT * column + nt, so a lane owns NT
+    // consecutive channels of each of its 16 pixels: one 4 NT-byte store per pixel, a pixel's Cout channels are contiguous
+    float* yp = a.Y + (size_t)tile * 32 * a.Cout + NT * li;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int r = 0; r < 16; ++r) {
+      typedef float vecn __attribute__((ext_vector_type(NT)));
+      const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      float v[NT];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
-        const float v = acc[nt][r] + bv[nt];
-        ssum[nt] += v;
-        ssq[nt] = __builtin_fmaf(v, v, ssq[nt]);
-        yp[(size_t)p * a.Cout + nt * 32] = v;
+      for (int nt = 0; nt < NT; ++nt) {
+        v[nt] = acc[nt][r] + bv[nt];
+        ssum[nt] += v[nt];
+        ssq[nt] = __builtin_fmaf(v[nt], v[nt], ssq[nt]);
+      }
+      if constexpr (NT == 1) {
+        yp[(size_t)p * a.Cout] = v[0];
+      } else {
+        vecn o;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = v[nt];
+        *(vecn*)(yp + (size_t)p * a.Cout) = o;
       }
     }
 #pragma unroll
@@ -109,8 +120,8 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
     for (int nt = 0; nt < NT; ++nt) {
       const float s1 = ssum[nt] + __shfl_xor(ssum[nt], 32, 64), s2 = ssq[nt] + __shfl_xor(ssq[nt], 32, 64);
       if (lh == 0) {
-        atomicAdd(st + 2 * (nt * 32 + li), (double)s1);
-        atomicAdd(st + 2 * (nt * 32 + li) + 1, (double)s2);
+        atomicAdd(st + 2 * (NT * li + nt), (double)s1);
+        atomicAdd(st + 2 * (NT * li + nt) + 1, (double)s2);
       }
     }
   }
