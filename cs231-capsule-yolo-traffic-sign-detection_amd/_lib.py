@@ -55,7 +55,7 @@ _SIGS = {
     'cy_conv_wgrad': [C.POINTER(ConvWgrad), _P],
     'cy_channel_sum': [_P, _P, _L, _I, _P],
     'cy_wino_pack_weights': [_P, _P, _I, _I, _I, _P],
-    'cy_conv1_3x3_fwd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    'cy_conv1_3x3_fwd': [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
     'cy_conv1_3x3_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],

@@ -18,11 +18,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Conv1Args {
   const float* X; const float* W; const float* bias; float* Y; double* stats;
+  const float* scale; const float* shift; float slope;   // forward only, optional: Y = lrelu((conv + bias) * scale + shift)
   int B, H, Wd, Cout;
   long long ntiles;                         // B * H * Wd / 32
 };
 
-template <int NT>
+template <int NT, bool AFF>
 __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -52,6 +53,15 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
   float ssum[NT], ssq[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) { ssum[nt] = 0.f; ssq[nt] = 0.f; }
+  // optional BatchNorm affine + LeakyReLU on the way out (second pass of a conv -> BN -> LeakyReLU block: the layer is
+  // store-bound and its input tiny, so recomputing the convolution is cheaper than reading z back): folded into bias
+  constexpr bool aff = AFF;                 // compile time: a uniform branch per element would cost more than the layer
+  float asc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    asc[nt] = aff ? a.scale[NT * li + nt] : 1.f;
+    if (aff) bv[nt] = bv[nt] * asc[nt] + a.shift[NT * li + nt];
+  }
 
   auto load_a = [&](long long tile, float (&av)[14]) {
     const int seg = (int)(tile % segs);
@@ -98,9 +108,15 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
       float v[NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        v[nt] = acc[nt][r] + bv[nt];
-        ssum[nt] += v[nt];
-        ssq[nt] = __builtin_fmaf(v[nt], v[nt], ssq[nt]);
+        if (aff) {
+          const float y = __builtin_fmaf(acc[nt][r], asc[nt], bv[nt]);
+          const float ys = y * a.slope;                         // slope in [0, 1]: lrelu(y) = max(y, slope y)
+          asm("v_max_f32 %0, %1, %2" : "=v"(v[nt]) : "v"(y), "v"(ys));   // fmaxf() would canonicalise both operands first
+        } else {
+          v[nt] = acc[nt][r] + bv[nt];
+          ssum[nt] += v[nt];
+          ssq[nt] = __builtin_fmaf(v[nt], v[nt], ssq[nt]);
+        }
       }
       if constexpr (NT == 1) {
         yp[(size_t)p * a.Cout] = v[0];
@@ -246,6 +262,7 @@ extern "C" int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, fl
   CY_REQUIRE((long long)3 * H * Wd < (1ll << 30), "cy_conv1_3x3_wgrad: image too large for 32-bit offsets");
   Conv1Args a;
   a.X = X; a.W = nullptr; a.bias = nullptr; a.Y = const_cast<float*>(dZ); a.stats = nullptr;
+  a.scale = a.shift = nullptr; a.slope = 1.f;
   a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout;
   a.ntiles = (long long)B * H * (Wd / 32);
   long long blocks = 0;
@@ -261,23 +278,34 @@ extern "C" int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, fl
   return 0;
 }
 
-extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats, int B, int H,
-                                int Wd, int Cout, void* stream) {
+extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats,
+                                const float* scale, const float* shift, float slope, int B, int H, int Wd, int Cout,
+                                void* stream) {
   CY_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0, "cy_conv1_3x3_fwd: bad arguments");
+  CY_REQUIRE((scale == nullptr) == (shift == nullptr), "cy_conv1_3x3_fwd: scale and shift go together");
+  CY_REQUIRE(scale == nullptr || (stats == nullptr && slope >= 0.f && slope <= 1.f),
+             "cy_conv1_3x3_fwd: the affine pass takes no statistics and a slope in [0, 1]");
   CY_REQUIRE(Wd % 32 == 0, "cy_conv1_3x3_fwd: W=%d must be a multiple of 32", Wd);
   CY_REQUIRE(Cout == 32 || Cout == 64 || Cout == 128, "cy_conv1_3x3_fwd: Cout=%d must be 32, 64 or 128", Cout);
   CY_REQUIRE((long long)3 * H * Wd < (1ll << 30), "cy_conv1_3x3_fwd: image too large for 32-bit offsets");
   Conv1Args a;
   a.X = X; a.W = W; a.bias = bias; a.Y = Y; a.stats = stats;
+  a.scale = scale; a.shift = shift; a.slope = slope;
   a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout;
   a.ntiles = (long long)B * H * (Wd / 32);
   long long blocks = 0;
   int rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_3x3_fwd");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  if (Cout == 128) conv1_fwd_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(a);
-  else if (Cout == 64) conv1_fwd_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a);
-  else conv1_fwd_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(a);
+#define CY_CONV1_LAUNCH(NT_)                                                                  \
+  do {                                                                                         \
+    if (scale) conv1_fwd_kernel<NT_, true><<<(unsigned)blocks, 256, 0, s>>>(a);                \
+    else conv1_fwd_kernel<NT_, false><<<(unsigned)blocks, 256, 0, s>>>(a);                     \
+  } while (0)
+  if (Cout == 128) CY_CONV1_LAUNCH(4);
+  else if (Cout == 64) CY_CONV1_LAUNCH(2);
+  else CY_CONV1_LAUNCH(1);
+#undef CY_CONV1_LAUNCH
   CY_LAUNCH_CHECK("cy_conv1_3x3_fwd");
   return 0;
 }

@@ -114,6 +114,24 @@ def _winograd(x, weight, bias, stats, transpose, tag):
     return y
 
 
+def conv1_ok(x, weight, k, stride, pad, nchw):
+    """The dedicated first-layer kernels (csrc/conv1.hip) apply: 3 -> {32, 64, 128} channels, 3x3 s1 p1, NCHW image."""
+    return (USE_CONV1 and nchw and k == 3 and stride == 1 and pad == 1 and x.dim() == 4 and x.shape[1] == 3
+            and weight.shape[0] in (32, 64, 128) and x.shape[3] % 32 == 0 and x.is_contiguous())
+
+
+def conv1_affine_act(x, weight, bias, scale, shift, slope, tag='conv'):
+    """lrelu((conv(x) + bias) * scale + shift) in one pass of the first-layer kernel (the second pass of its conv ->
+    BatchNorm -> LeakyReLU block: recomputing the layer costs less than reading its 2.8 GB output back)."""
+    B, _, Hi, Wi = x.shape
+    Cout = weight.shape[0]
+    out = _empty((B, Hi, Wi, Cout), x)
+    with timer.range('conv1_fwd_act/' + tag):
+        call('cy_conv1_3x3_fwd', _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(out), None, _ptr(scale), _ptr(shift),
+             float(slope), B, Hi, Wi, Cout, _stream())
+    return out
+
+
 def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv', in_affine=None):
     """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
     x, weight = _f32(x, 'conv input'), _f32(weight, 'conv weight')
@@ -136,13 +154,13 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
             call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
                  float(isl), B, Hi, Wi, Cin, Cout, st)
         return y
-    if (USE_CONV1 and nchw and k == 3 and stride == 1 and pad == 1 and Cin == 3 and Cout in (32, 64, 128) and Wi % 32 == 0
-            and not relu and x.is_contiguous()):
+    if not relu and conv1_ok(x, weight, k, stride, pad, nchw):
         # the backbones' first layer (store-bound): persistent waves, operands from registers / L2
         st = _stream()
         z = _empty((B, Ho, Wo, Cout), x)
         with timer.range('conv1_fwd/' + tag):
-            call('cy_conv1_3x3_fwd', _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(z), _ptr(stats), B, Hi, Wi, Cout, st)
+            call('cy_conv1_3x3_fwd', _ptr(x), _ptr(weight.contiguous()), _ptr(bias), _ptr(z), _ptr(stats), None, None, 1.0,
+                 B, Hi, Wi, Cout, st)
         return z
     st = _stream()
     wp = _empty((query('cy_conv_packed_floats', k * k * Cin, Cout),), x)
@@ -340,6 +358,8 @@ class _ConvBlock(torch.autograd.Function):
             ctx.holder = cfg.out_holder = {'mean': mean, 'invstd': invstd, 'red': None} if ctx.bn_train else None
             return z, scale, shift
         ctx.holder = None
+        if conv1_ok(x, weight, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in) and 0.0 <= slope <= 1.0:
+            return conv1_affine_act(x, weight, bias, scale, shift, slope, cfg.name)
         out = torch.empty_like(z)
         call('cy_affine_act', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), slope, P, N, st)
         return out
