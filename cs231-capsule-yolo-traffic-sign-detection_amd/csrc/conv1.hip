@@ -226,6 +226,176 @@ __global__ __launch_bounds__(256, 1) void conv1_wgrad_kernel(Conv1Args a, float*
     }
 }
 
+// ---- backward of the whole first block (conv -> BatchNorm -> LeakyReLU) without z and without dz in memory.
+// The block's z (2.8 GB) would be read twice (BatchNorm-backward sums, then the apply pass) and dz written and read once
+// more by the weight gradient; instead both passes RECOMPUTE z = conv(x) + bias per 32-pixel tile (56 MFMAs, the image
+// is L2-resident) and read only dA, the gradient with respect to the activation:
+//   PASS 0: red[c] += (sum d, sum d * xhat), d = dA * lrelu'(z * scale + shift), xhat = (z - mean) * invstd
+//   PASS 1: dz = scale * (d - m1 - xhat * m2) (m = red / count) is formed in registers IN THE LAYOUT the weight-gradient
+//           MFMA wants: the accumulator of the recomputed tile has lane = channel column, 16 pixel rows p(r, half), and the
+//           weight gradient's k dimension (pixels) may be enumerated in any order, so step s takes pixel p(s, half) --
+//           the lane's own accumulator row s -- and the image operand is fetched for the same pixel.
+struct Conv1BnArgs {
+  const float* X; const float* W; const float* bias; const float* dA;
+  const float* scale; const float* shift; const float* mean; const float* invstd; float slope;
+  double* red_out;                          // PASS 0: [CY_STATS_COPIES][Cout][2], zeroed by the caller
+  const double* red_in; double inv_count;   // PASS 1: [Cout][2] summed (and, for SyncBN, averaged) by the caller
+  float* slabs;                             // PASS 1: per-wave partial dW
+  int B, H, Wd, Cout;
+  long long ntiles;
+};
+
+template <int NT, int PASS>
+__global__ __launch_bounds__(256, 1) void conv1_bn_bwd_kernel(Conv1BnArgs a) {
+  typedef float vecn __attribute__((ext_vector_type(NT)));
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  const int segs = a.Wd / 32;
+  const size_t plane = (size_t)a.H * a.Wd;
+  // forward operand geometry (conv1_fwd_kernel): lane = pixel li, step s = taps 2 s + lh
+  int toff[14], tky[14], tkx[14];
+  float wreg[NT][14];
+#pragma unroll
+  for (int s = 0; s < 14; ++s) {
+    const int k = 2 * s + lh;
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, kh = (kk % 9) / 3, kw = kk % 3;
+    tky[s] = k < 27 ? kh - 1 : (1 << 20);
+    tkx[s] = kw - 1;
+    toff[s] = (int)(c * plane) + (kh - 1) * a.Wd + (kw - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[nt][s] = k < 27 ? a.W[((size_t)(NT * li + nt) * 3 + c) * 9 + kh * 3 + kw] : 0.f;
+  }
+  // weight-gradient operand geometry (conv1_wgrad_kernel): lane = tap li, step s = pixel p(s, lh)
+  const int kt = li < 27 ? li : 0;
+  const int wc = kt / 9, wkh = (kt % 9) / 3, wkw = kt % 3;
+  const int woff = (int)(wc * plane) + (wkh - 1) * a.Wd + (wkw - 1) + 4 * lh;    // + (s & 3) + 8 (s >> 2)
+  // per-channel constants of this lane's NT channels
+  float bv[NT], sc[NT], sh[NT], is[NT], nm[NT], m1[NT], m2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = NT * li + nt;
+    bv[nt] = a.bias != nullptr ? a.bias[c] : 0.f;
+    sc[nt] = a.scale[c]; sh[nt] = a.shift[c]; is[nt] = a.invstd[c]; nm[nt] = -a.mean[c] * is[nt];
+    m1[nt] = PASS == 1 ? (float)(a.red_in[2 * c] * a.inv_count) : 0.f;
+    m2[nt] = PASS == 1 ? (float)(a.red_in[2 * c + 1] * a.inv_count) : 0.f;
+  }
+  float b1[NT], b2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) { b1[nt] = 0.f; b2[nt] = 0.f; }
+
+  auto load_img = [&](long long tile, float (&av)[14], float (&bw)[16]) {
+    const int seg = (int)(tile % segs);
+    const long long row = tile / segs;
+    const int y = (int)(row % a.H), b = (int)(row / a.H);
+    const float* p0 = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + seg * 32;
+    const float* px = p0 + li;
+    const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;    // uniform
+    if (inner) {
+#pragma unroll
+      for (int s = 0; s < 14; ++s) av[s] = (s < 13 || lh == 0) ? px[toff[s]] : 0.f;
+      if (PASS == 1) {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) bw[s] = p0[woff + (s & 3) + 8 * (s >> 2)];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 14; ++s) {
+        const bool ok = (unsigned)(y + tky[s]) < (unsigned)a.H && (unsigned)(seg * 32 + li + tkx[s]) < (unsigned)a.Wd;
+        const float v = px[ok ? toff[s] : 0];
+        av[s] = ok ? v : 0.f;
+      }
+      if (PASS == 1) {
+        const bool rowok = (unsigned)(y + wkh - 1) < (unsigned)a.H;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const int pcol = (s & 3) + 8 * (s >> 2) + 4 * lh;
+          const bool ok = rowok && (unsigned)(seg * 32 + pcol + wkw - 1) < (unsigned)a.Wd;
+          const float v = p0[ok ? woff + (s & 3) + 8 * (s >> 2) : 0];
+          bw[s] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+
+  f32x16 accw[NT];                          // PASS 1: dW[channel NT row + nt][tap]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[nt][r] = 0.f;
+  float acur[14], anext[14], bwcur[16], bwnext[16];
+  long long tile = gw;
+  if (tile < a.ntiles) load_img(tile, acur, bwcur);
+  for (; tile < a.ntiles; tile += nw) {
+    // dA of this tile in the accumulator layout: requested first, used after the 14 NT recompute MFMAs
+    const float* pg = a.dA + (size_t)tile * 32 * a.Cout + NT * li;
+    vecn g[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) g[r] = *(const vecn*)(pg + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.Cout);
+    const long long tn = tile + nw;
+    if (tn < a.ntiles) load_img(tn, anext, bwnext);
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 14; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(acur[s], wreg[nt][s], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float dzr[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float z = acc[nt][r] + bv[nt];
+        const float y = __builtin_fmaf(z, sc[nt], sh[nt]);
+        const float gv = ((const float*)&g[r])[nt];
+        const float d = y > 0.f ? gv : gv * a.slope;
+        const float xh = __builtin_fmaf(z, is[nt], nm[nt]);
+        if (PASS == 0) {
+          b1[nt] += d;
+          b2[nt] = __builtin_fmaf(d, xh, b2[nt]);
+        } else {
+          dzr[nt] = sc[nt] * (d - m1[nt] - xh * m2[nt]);
+        }
+      }
+      if (PASS == 1) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) accw[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(dzr[nt], bwcur[r], accw[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 14; ++s) acur[s] = anext[s];
+    if (PASS == 1) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) bwcur[s] = bwnext[s];
+    }
+  }
+  if (PASS == 0) {
+    double* rd = a.red_out + (size_t)((blockIdx.x * 4 + wave) % CY_STATS_COPIES) * a.Cout * 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float s1 = b1[nt] + __shfl_xor(b1[nt], 32, 64), s2 = b2[nt] + __shfl_xor(b2[nt], 32, 64);
+      if (lh == 0) {
+        atomicAdd(rd + 2 * (NT * li + nt), (double)s1);
+        atomicAdd(rd + 2 * (NT * li + nt) + 1, (double)s2);
+      }
+    }
+  } else {
+    float* out = a.slabs + (size_t)gw * a.Cout * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = NT * ((r & 3) + 8 * (r >> 2) + 4 * lh) + nt;
+        out[(size_t)co * 32 + li] = accw[nt][r];
+      }
+  }
+}
+
 // dW[co][c][kh][kw] (= [co][27]) = sum over the waves' slabs, in slab order
 __global__ void conv1_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int nslab, int Cout) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -275,6 +445,66 @@ extern "C" int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, fl
   CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad");
   conv1_wgrad_finish_kernel<<<(Cout * 27 + 255) / 256, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
   CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad (finish)");
+  return 0;
+}
+
+static int conv1_bn_check(const char* who, const float* X, const float* W, const float* dA, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, float slope, int B, int H, int Wd,
+                          int Cout) {
+  CY_REQUIRE(X && W && dA && scale && shift && mean && invstd && B > 0 && H > 0 && Wd > 0, "%s: bad arguments", who);
+  CY_REQUIRE(Wd % 32 == 0, "%s: W=%d must be a multiple of 32", who, Wd);
+  CY_REQUIRE(Cout == 32 || Cout == 64 || Cout == 128, "%s: Cout=%d must be 32, 64 or 128", who, Cout);
+  CY_REQUIRE((long long)3 * H * Wd < (1ll << 30), "%s: image too large for 32-bit offsets", who);
+  CY_REQUIRE(slope >= 0.f && slope <= 1.f, "%s: slope must be in [0, 1]", who);
+  return 0;
+}
+
+extern "C" int cy_conv1_bn_bwd_reduce(const float* X, const float* W, const float* bias, const float* dA, const float* scale,
+                                      const float* shift, const float* mean, const float* invstd, float slope, double* red,
+                                      int B, int H, int Wd, int Cout, void* stream) {
+  int rc = conv1_bn_check("cy_conv1_bn_bwd_reduce", X, W, dA, scale, shift, mean, invstd, slope, B, H, Wd, Cout);
+  if (rc) return rc;
+  CY_REQUIRE(red != nullptr, "cy_conv1_bn_bwd_reduce: red is NULL");
+  Conv1BnArgs a;
+  a.X = X; a.W = W; a.bias = bias; a.dA = dA; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.slope = slope; a.red_out = red; a.red_in = nullptr; a.inv_count = 0.0; a.slabs = nullptr;
+  a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout; a.ntiles = (long long)B * H * (Wd / 32);
+  long long blocks = 0;
+  rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_bn_bwd_reduce");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout == 128) conv1_bn_bwd_kernel<4, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else if (Cout == 64) conv1_bn_bwd_kernel<2, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else conv1_bn_bwd_kernel<1, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+  CY_LAUNCH_CHECK("cy_conv1_bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" long long cy_conv1_bn_bwd_wgrad_ws_floats(int B, int H, int Wd, int Cout) {
+  return cy_conv1_3x3_wgrad_ws_floats(B, H, Wd, Cout);
+}
+
+extern "C" int cy_conv1_bn_bwd_wgrad(const float* X, const float* W, const float* bias, const float* dA, const float* scale,
+                                     const float* shift, const float* mean, const float* invstd, float slope,
+                                     const double* red, long long count, float* dW, float* ws, int B, int H, int Wd,
+                                     int Cout, void* stream) {
+  int rc = conv1_bn_check("cy_conv1_bn_bwd_wgrad", X, W, dA, scale, shift, mean, invstd, slope, B, H, Wd, Cout);
+  if (rc) return rc;
+  CY_REQUIRE(red && dW && ws && count > 0, "cy_conv1_bn_bwd_wgrad: bad arguments");
+  Conv1BnArgs a;
+  a.X = X; a.W = W; a.bias = bias; a.dA = dA; a.scale = scale; a.shift = shift; a.mean = mean; a.invstd = invstd;
+  a.slope = slope; a.red_out = nullptr; a.red_in = red; a.inv_count = 1.0 / (double)count; a.slabs = ws;
+  a.B = B; a.H = H; a.Wd = Wd; a.Cout = Cout; a.ntiles = (long long)B * H * (Wd / 32);
+  long long blocks = 0;
+  rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_bn_bwd_wgrad");
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  if (Cout == 128) conv1_bn_bwd_kernel<4, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else if (Cout == 64) conv1_bn_bwd_kernel<2, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else conv1_bn_bwd_kernel<1, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+  CY_LAUNCH_CHECK("cy_conv1_bn_bwd_wgrad");
+  conv1_wgrad_finish_kernel<<<(Cout * 27 + 255) / 256, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
+  CY_LAUNCH_CHECK("cy_conv1_bn_bwd_wgrad (finish)");
   return 0;
 }
 

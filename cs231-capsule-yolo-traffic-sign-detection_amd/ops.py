@@ -79,6 +79,7 @@ def _x_geometry(x, nchw):
 
 
 STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
+USE_CONV1_BWD = True     # ... and the backward of its whole conv -> BatchNorm -> LeakyReLU block without z / dz in memory
 USE_CONV1 = True         # 3 -> {32, 64, 128} channels, 3x3, NCHW image (the backbones' first layer): dedicated store-bound kernels
 USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short reductions; kept switchable)
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
@@ -350,7 +351,7 @@ class _ConvBlock(torch.autograd.Function):
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                  float(bn.eps), _ptr(scale), _ptr(shift), N, st)
         slope = 1.0 if cfg.slope is None else float(cfg.slope)
-        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma)
+        ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma, *([bias] if bias is not None else []))
         if cfg.defer_act:                     # the consumer block applies lrelu(z * scale + shift) on its loads
             ctx.mark_non_differentiable(scale, shift)
             # hand-over for the backward: the consumer's input-gradient kernel can also produce this block's
@@ -388,6 +389,29 @@ class _ConvBlock(torch.autograd.Function):
                 raise _lib.HipExtensionError('backward through an eval-mode BatchNorm block is not implemented')
             scale, shift, mean, invstd, gamma = saved[3:8]
             slope = 1.0 if cfg.slope is None else float(cfg.slope)
+            if (USE_CONV1_BWD and ctx.holder is None and not ctx.needs_input_grad[0] and 0.0 <= slope <= 1.0
+                    and conv1_ok(x, weight, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in) and da.is_contiguous()):
+                # the first block: both BatchNorm-backward passes recompute z tile by tile and read only da; dz is
+                # formed in registers in the layout the weight-gradient MFMA consumes (csrc/conv1.hip)
+                bias_t = saved[8] if ctx.has_bias else None
+                B, _, Hi, Wi = x.shape
+                redc = torch.zeros((STATS_COPIES, N, 2), dtype=torch.float64, device=z.device)
+                with timer.range('conv1_bn_bwd_reduce/' + cfg.name):
+                    call('cy_conv1_bn_bwd_reduce', _ptr(x), _ptr(weight), _ptr(bias_t), _ptr(da), _ptr(scale), _ptr(shift),
+                         _ptr(mean), _ptr(invstd), slope, _ptr(redc), B, Hi, Wi, N, st)
+                red = redc.sum(0)
+                dist, world = _sync_world()
+                if dist is not None:
+                    dist.all_reduce(red)
+                    red /= world
+                dbeta, dgamma = red[:, 0].float().contiguous(), red[:, 1].float().contiguous()
+                dW = _empty(tuple(weight.shape), z)
+                ws = _empty((query('cy_conv1_bn_bwd_wgrad_ws_floats', B, Hi, Wi, N),), z)
+                with timer.range('conv1_bn_bwd_wgrad/' + cfg.name):
+                    call('cy_conv1_bn_bwd_wgrad', _ptr(x), _ptr(weight), _ptr(bias_t), _ptr(da), _ptr(scale), _ptr(shift),
+                         _ptr(mean), _ptr(invstd), slope, _ptr(red), P, _ptr(dW), _ptr(ws), B, Hi, Wi, N, st)
+                dbias = torch.zeros((N,), dtype=torch.float32, device=z.device) if ctx.has_bias else None
+                return None, dW, dbias, dgamma, dbeta, None, None, None
             if ctx.holder is not None and ctx.holder.get('red') is not None:
                 red = ctx.holder['red']        # summed by the consumer block's input-gradient epilogues
                 ctx.holder['red'] = None

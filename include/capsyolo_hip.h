@@ -70,6 +70,19 @@ int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y
  * fixed order: deterministic). */
 long long cy_conv1_3x3_wgrad_ws_floats(int B, int H, int Wd, int Cout);
 int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, float* ws, int B, int H, int Wd, int Cout, void* stream);
+/* Backward of that layer's whole conv -> BatchNorm -> LeakyReLU block from dA, the gradient with respect to the activation
+ * (nn.Conv2d / nn.BatchNorm2d / nn.LeakyReLU backward, models.py:347-348), without z and dz in memory: both passes
+ * recompute z = conv(X) + bias tile by tile.  Pass 1: red[CY_STATS_COPIES][Cout][2] (zeroed by the caller) += (sum d,
+ * sum d xhat) like cy_bn_bwd_reduce.  Pass 2: with red[Cout][2] summed over the copies (and ranks) and count = pixels per
+ * channel of the (global) batch, dW[Cout][3][3][3] = weight gradient of dz = scale (d - red0/count - xhat red1/count);
+ * dgamma = red1, dbeta = red0 as in cy_bn_bwd_apply.  ws: cy_conv1_bn_bwd_wgrad_ws_floats floats. */
+int cy_conv1_bn_bwd_reduce(const float* X, const float* W, const float* bias, const float* dA, const float* scale,
+                           const float* shift, const float* mean, const float* invstd, float slope, double* red, int B, int H,
+                           int Wd, int Cout, void* stream);
+long long cy_conv1_bn_bwd_wgrad_ws_floats(int B, int H, int Wd, int Cout);
+int cy_conv1_bn_bwd_wgrad(const float* X, const float* W, const float* bias, const float* dA, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, float slope, const double* red,
+                          long long count, float* dW, float* ws, int B, int H, int Wd, int Cout, void* stream);
 
 /* number of floats of a packed-weight buffer for (K = TH*TW*Cin, N) */
 long long cy_conv_packed_floats(int K, int N);

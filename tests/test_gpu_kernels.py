@@ -334,6 +334,62 @@ def test_conv_bn_lrelu_block(train, cin, cout, hw, B):
         assert float(seq.conv_1.bias.grad.abs().max()) == 0.0       # analytically zero in front of BN
 
 
+@pytest.mark.parametrize('cout,H,W,B', [(128, 32, 32, 2), (32, 33, 64, 3), (64, 6, 96, 1)])
+def test_first_block_fused_backward(cout, H, W, B):
+    """Image -> Conv(3, cout, 3, 1, 1) -> BatchNorm2d -> LeakyReLU(0.1): the first block's fused paths (second forward pass
+    with the activation, backward passes that recompute z: cy_conv1_bn_bwd_reduce / _wgrad) vs torch fp64 modules and
+    vs the generic kernels."""
+    from capsyolo_amd import models, ops
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(3, cout, 3, 1, 1).double()
+    bn = torch.nn.BatchNorm2d(cout).double()
+    bn.weight.data = 1 + 0.2 * torch.randn(cout).double()
+    bn.bias.data = 0.1 * torch.randn(cout).double()
+    ref = torch.nn.Sequential(conv, bn, torch.nn.LeakyReLU(0.1)).train()
+    x = rnd((B, 3, H, W), 141)
+    g = rnd((B, cout, H, W), 142)
+    yr = ref(x.double())
+    yr.backward(g.double())
+
+    def run():
+        seq = models.FusedBackbone()
+        seq.add_module('conv_1', models.HipConv2d(3, cout, 3, 1, 1))
+        seq.add_module('bn_1', models.HipBatchNorm2d(cout))
+        seq.add_module('relu_1', models.HipLeakyReLU(0.1))
+        seq.conv_1.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
+        sd = torch.nn.BatchNorm2d(cout).state_dict()
+        sd['weight'], sd['bias'] = bn.weight.data.float(), bn.bias.data.float()
+        seq.bn_1.load_state_dict(sd)
+        seq.to(dev()).train()
+        ops.timer.reset(); ops.timer.enabled = True
+        try:
+            yh = seq(x.to(dev()), nchw_in=True)
+            yh.backward(g.permute(0, 2, 3, 1).contiguous().to(dev()))
+            torch.cuda.synchronize()
+            keys = set(ops.timer.summary())
+        finally:
+            ops.timer.enabled = False
+        return seq, yh, keys
+    seq, yh, keys = run()
+    assert any(k.startswith('conv1_bn_bwd_wgrad/') for k in keys) and any(k.startswith('conv1_fwd_act/') for k in keys)
+    close(yh.permute(0, 3, 1, 2), yr, 1e-4, 1e-5)
+    close(seq.bn_1.running_mean, bn.running_mean, 1e-4, 1e-6)
+    close(seq.conv_1.weight.grad, conv.weight.grad, 1e-3, 1e-4)
+    close(seq.bn_1.weight.grad, bn.weight.grad, 1e-3, 1e-4)
+    close(seq.bn_1.bias.grad, bn.bias.grad, 1e-3, 1e-4)
+    assert float(seq.conv_1.bias.grad.abs().max()) == 0.0
+    ops.USE_CONV1_BWD = ops.USE_CONV1 = False
+    try:
+        seq0, yh0, keys0 = run()
+    finally:
+        ops.USE_CONV1_BWD = ops.USE_CONV1 = True
+    assert not any(k.startswith('conv1_') for k in keys0)
+    close(yh, yh0, 1e-5, 1e-5)
+    close(seq.conv_1.weight.grad, seq0.conv_1.weight.grad, 1e-4, 1e-4)
+    close(seq.bn_1.weight.grad, seq0.bn_1.weight.grad, 1e-4, 1e-4)
+    close(seq.bn_1.bias.grad, seq0.bn_1.bias.grad, 1e-4, 1e-4)
+
+
 # ------------------------------------------------------------------------------------------------ routing
 @pytest.mark.parametrize('ci', [0, 1, 2, 3])
 @pytest.mark.parametrize('n_iter', [1, 3, 5])
