@@ -23,7 +23,7 @@ struct Conv1Args {
   long long ntiles;                         // B * H * Wd / 32
 };
 
-template <int NT, bool AFF>
+template <int NT, bool AFF, bool STORE>
 __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -118,7 +118,9 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
           ssq[nt] = __builtin_fmaf(v[nt], v[nt], ssq[nt]);
         }
       }
-      if constexpr (NT == 1) {
+      if constexpr (!STORE) {
+        (void)p;                            // statistics only: z is recomputed wherever it is needed
+      } else if constexpr (NT == 1) {
         yp[(size_t)p * a.Cout] = v[0];
       } else {
         vecn o;
@@ -511,7 +513,7 @@ extern "C" int cy_conv1_bn_bwd_wgrad(const float* X, const float* W, const float
 extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bias, float* Y, double* stats,
                                 const float* scale, const float* shift, float slope, int B, int H, int Wd, int Cout,
                                 void* stream) {
-  CY_REQUIRE(X && W && Y && B > 0 && H > 0 && Wd > 0, "cy_conv1_3x3_fwd: bad arguments");
+  CY_REQUIRE(X && W && (Y || (stats && !scale)) && B > 0 && H > 0 && Wd > 0, "cy_conv1_3x3_fwd: bad arguments");
   CY_REQUIRE((scale == nullptr) == (shift == nullptr), "cy_conv1_3x3_fwd: scale and shift go together");
   CY_REQUIRE(scale == nullptr || (stats == nullptr && slope >= 0.f && slope <= 1.f),
              "cy_conv1_3x3_fwd: the affine pass takes no statistics and a slope in [0, 1]");
@@ -529,8 +531,9 @@ extern "C" int cy_conv1_3x3_fwd(const float* X, const float* W, const float* bia
   hipStream_t s = (hipStream_t)stream;
 #define CY_CONV1_LAUNCH(NT_)                                                                  \
   do {                                                                                         \
-    if (scale) conv1_fwd_kernel<NT_, true><<<(unsigned)blocks, 256, 0, s>>>(a);                \
-    else conv1_fwd_kernel<NT_, false><<<(unsigned)blocks, 256, 0, s>>>(a);                     \
+    if (scale) conv1_fwd_kernel<NT_, true, true><<<(unsigned)blocks, 256, 0, s>>>(a);          \
+    else if (Y) conv1_fwd_kernel<NT_, false, true><<<(unsigned)blocks, 256, 0, s>>>(a);        \
+    else conv1_fwd_kernel<NT_, false, false><<<(unsigned)blocks, 256, 0, s>>>(a);              \
   } while (0)
   if (Cout == 128) CY_CONV1_LAUNCH(4);
   else if (Cout == 64) CY_CONV1_LAUNCH(2);

@@ -333,10 +333,23 @@ class _ConvBlock(torch.autograd.Function):
             return out
         scale, shift = _empty((N,), x), _empty((N,), x)
         mean, invstd = _empty((N,), x), _empty((N,), x)
+        slope = 1.0 if cfg.slope is None else float(cfg.slope)
+        # the first block (csrc/conv1.hip): z is never written -- this pass only takes the statistics, the activation
+        # pass and both backward passes recompute the convolution
+        ctx.conv1_fused = bool(USE_CONV1_BWD and bn.training and not cfg.defer_act and not x.requires_grad
+                               and 0.0 <= slope <= 1.0 and conv1_ok(x, weight, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in))
         if bn.training:
             stats = torch.zeros((STATS_COPIES, N, 2), dtype=torch.float64, device=x.device)
-            z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name, ina)
-            P = z.numel() // N
+            if ctx.conv1_fused:
+                Bx, _, Hx, Wx = x.shape
+                with timer.range('conv1_fwd_stats/' + cfg.name):
+                    call('cy_conv1_3x3_fwd', _ptr(x), _ptr(weight.contiguous()), _ptr(bias), None, _ptr(stats), None, None, 1.0,
+                         Bx, Hx, Wx, N, st)
+                z = x.new_empty(0)
+                P = Bx * Hx * Wx
+            else:
+                z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, stats, False, cfg.name, ina)
+                P = z.numel() // N
             dist, world = _sync_world()
             if dist is not None:              # sum z / sum z^2 over the global batch (equal shards: dp.shard_range)
                 dist.all_reduce(stats)
@@ -350,7 +363,7 @@ class _ConvBlock(torch.autograd.Function):
             P = z.numel() // N
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                  float(bn.eps), _ptr(scale), _ptr(shift), N, st)
-        slope = 1.0 if cfg.slope is None else float(cfg.slope)
+        ctx.P = P
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd, gamma, *([bias] if bias is not None else []))
         if cfg.defer_act:                     # the consumer block applies lrelu(z * scale + shift) on its loads
             ctx.mark_non_differentiable(scale, shift)
@@ -373,7 +386,7 @@ class _ConvBlock(torch.autograd.Function):
         saved = ctx.saved_tensors
         x, weight, z = saved[0], saved[1], saved[2]
         N = weight.shape[0]
-        P = z.numel() // N
+        P = ctx.P if cfg.bn is not None else z.numel() // N
         dgamma = dbeta = dbias = None
         if cfg.bn is None:
             if cfg.slope is not None:
@@ -389,8 +402,8 @@ class _ConvBlock(torch.autograd.Function):
                 raise _lib.HipExtensionError('backward through an eval-mode BatchNorm block is not implemented')
             scale, shift, mean, invstd, gamma = saved[3:8]
             slope = 1.0 if cfg.slope is None else float(cfg.slope)
-            if (USE_CONV1_BWD and ctx.holder is None and not ctx.needs_input_grad[0] and 0.0 <= slope <= 1.0
-                    and conv1_ok(x, weight, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in) and da.is_contiguous()):
+            if ctx.conv1_fused:
+                da = da.contiguous()
                 # the first block: both BatchNorm-backward passes recompute z tile by tile and read only da; dz is
                 # formed in registers in the layout the weight-gradient MFMA consumes (csrc/conv1.hip)
                 bias_t = saved[8] if ctx.has_bias else None

@@ -60,6 +60,7 @@ typedef struct {
 /* First layer of the backbones (models.py:347-349 DarkCapsuleNet conv_1 3 -> 128, models.py:132-136 DarkNet conv_1
  * 3 -> 32): 3x3 / stride 1 / pad 1 on the NCHW image X[B][3][H][W] (W % 32 == 0) with PyTorch-layout weights
  * W[Cout][3][3][3], Cout in {32, 64, 128}; Y[B][H][W][Cout] NHWC.  bias / stats as in cy_conv_gemm (either may be NULL).
+ * Y may be NULL when stats is given (statistics only: the block's backward recomputes z, cy_conv1_bn_bwd_*).
  * Optional scale / shift [Cout] and slope (then stats must be NULL): Y = lrelu((conv + bias) * scale + shift), the second
  * pass of a conv -> BatchNorm -> LeakyReLU block -- recomputing this layer is cheaper than reading its output back.
  * A store-bound layer: persistent waves, operands from registers / L2, no LDS. */
