@@ -398,14 +398,22 @@ __global__ __launch_bounds__(256, 1) void conv1_bn_bwd_kernel(Conv1BnArgs a) {
   }
 }
 
-// dW[co][c][kh][kw] (= [co][27]) = sum over the waves' slabs, in slab order
-__global__ void conv1_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dW, int nslab, int Cout) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= Cout * 27) return;
-  const int co = idx / 27, k = idx - co * 27;
+// dW[co][c][kh][kw] (= [co][27]) = sum over the waves' slabs in a fixed order: one block per channel, thread = (tap,
+// slab group): 128 contiguous bytes per slab row, 8 partial sums per tap combined through LDS
+__global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dW,
+                                                                 int nslab, int Cout) {
+  __shared__ float part[8][32];
+  const int co = blockIdx.x, tap = threadIdx.x & 31, grp = threadIdx.x >> 5;
   float s = 0.f;
-  for (int w = 0; w < nslab; ++w) s += slabs[((size_t)w * Cout + co) * 32 + k];
-  dW[idx] = s;
+  for (int w = grp; w < nslab; w += 8) s += slabs[((size_t)w * Cout + co) * 32 + tap];
+  part[grp][tap] = s;
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    float v = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += part[g][threadIdx.x];
+    dW[co * 27 + threadIdx.x] = v;
+  }
 }
 
 static int conv1_blocks(long long ntiles, long long* blocks, const char* who) {
@@ -445,7 +453,7 @@ extern "C" int cy_conv1_3x3_wgrad(const float* X, const float* dZ, float* dW, fl
   else if (Cout == 64) conv1_wgrad_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a, ws);
   else conv1_wgrad_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(a, ws);
   CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad");
-  conv1_wgrad_finish_kernel<<<(Cout * 27 + 255) / 256, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
+  conv1_wgrad_finish_kernel<<<Cout, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
   CY_LAUNCH_CHECK("cy_conv1_3x3_wgrad (finish)");
   return 0;
 }
@@ -505,7 +513,7 @@ extern "C" int cy_conv1_bn_bwd_wgrad(const float* X, const float* W, const float
   else if (Cout == 64) conv1_bn_bwd_kernel<2, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
   else conv1_bn_bwd_kernel<1, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv1_bn_bwd_wgrad");
-  conv1_wgrad_finish_kernel<<<(Cout * 27 + 255) / 256, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
+  conv1_wgrad_finish_kernel<<<Cout, 256, 0, s>>>(ws, dW, (int)(blocks * 4), Cout);
   CY_LAUNCH_CHECK("cy_conv1_bn_bwd_wgrad (finish)");
   return 0;
 }
