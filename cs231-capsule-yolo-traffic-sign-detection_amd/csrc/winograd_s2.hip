@@ -14,6 +14,12 @@
 // tiles x 32 channels x 9 positions = 18 accumulator tiles (288 registers); per chunk 72 MFMAs per wave, every other
 // piece of work (U / patch global loads, LDS stores, the input transform on channel pairs with v_pk_add_f32) in one
 // of the 72 slots between them.  9 global loads per 72 MFMAs (the 3x3 kernel has 11 per 64).
+//
+// Developer instrumentation, compiled out by default (tools/w2prof.py, tools/w2prof_fwd.py):
+//   -DW2_PROF    per-block cycle counts of the chunk loop / drain phases and s_memtime stamps inside one chunk per tile
+//                (the buffers are passed through otherwise unused arguments named by CY_W2_PROF / CY_W2_STAMPS)
+//   -DW2_SKIP=m  knock-out builds: bit 0 drops the input transform, bit 1 the LDS stores of U / patch, bit 2 the global
+//                loads, bit 3 reads every patch from the same L2-resident bytes (results are wrong: timing only)
 #include <type_traits>
 #ifndef W2_SKIP
 #define W2_SKIP 0
