@@ -237,7 +237,9 @@ def main():
             'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(1e3 * elapsed / args.steps, 3),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': 'experiments/darkcapsule GTSDB-shaped %dx%d, n_grid %d, %d routing iters, batch %d per GPU, '
-                                   'recon off, fp32 (BASELINE configs[2])' % (args.input, args.input, g, args.n_iter, B),
+                                   'recon off, fp32 (%s)' % (args.input, args.input, g, args.n_iter, B,
+                                                             'BASELINE configs[2]' if (args.input, args.n_iter, B) == (416, 3, 32)
+                                                             else 'not a BASELINE configuration'),
                        'global_batch': world * B, 'parallelism': 'dp%d%s' % (world, '+syncbn' if (args.sync_bn and world > 1) else ''), 'final_loss': round(final_loss, 6)},
             'roofline': cands[0] if cands else None,
             'roofline_other_conv2': cands[1:],
