@@ -22,7 +22,7 @@ class ConvGemm(C.Structure):
                 ('Hy', C.c_int), ('Wy', C.c_int), ('out_stride', C.c_int), ('out_oy', C.c_int), ('out_ox', C.c_int),
                 ('act', C.c_int),
                 ('bn_z', C.c_void_p), ('bn_scale', C.c_void_p), ('bn_shift', C.c_void_p), ('bn_mean', C.c_void_p),
-                ('bn_invstd', C.c_void_p), ('bn_red', C.c_void_p), ('bn_slope', C.c_float)]
+                ('bn_invstd', C.c_void_p), ('bn_red', C.c_void_p), ('bn_slope', C.c_float), ('act_slope', C.c_float)]
 
 
 class ConvWgrad(C.Structure):
@@ -65,18 +65,19 @@ _SIGS = {
     'cy_conv1_bn_bwd_wgrad': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     'cy_conv1_bn_bwd_wgrad_bf16': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     'cy_conv1_3x3_fwd_act_bf16': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
-    'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad_bn': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_bn_param_grad': [_P, _P, _P, _I, _P],
     'cy_wino2_pack_weights': [_P, _P, _I, _I, _P],
-    'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P],
     'cy_conv4x4s2_winograd_wgrad': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_wino2_pack_dgrad_weights': [_P, _P, _I, _I, _P],
     'cy_conv4x4s2_winograd_dgrad': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     'cy_bn_finalize': [_P, _L, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P, _P],
     'cy_bn_red_fold': [_P, _I, C.c_double, _P, _P, _P, _I, _P],
     'cy_bn_eval_scale_shift': [_P, _P, _P, _P, _F, _P, _P, _I, _P],
+    'cy_bn_fold_eval': [_P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _P],
     'cy_affine_act': [_P, _P, _P, _P, _F, _L, _I, _P],
     'cy_bn_bwd_reduce': [_P, _P, _P, _P, _P, _P, _F, _P, _L, _I, _P],
     'cy_bn_bwd_apply': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
@@ -139,6 +140,7 @@ _RET = {
     'cy_routing_fwd_ws_floats': (_L, [C.POINTER(RoutingFwd)]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
+ABI_VERSION = 3     # what the signatures above were written against (include/capsyolo_hip.h, csrc/error.cpp)
 
 _lib = None
 
@@ -157,6 +159,11 @@ def load():
             'libcapsyolo_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"` '
             'or `make -C cs231-capsule-yolo-traffic-sign-detection_amd/csrc`. There is no CPU fallback.' % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
+    lib.capsyolo_abi_version.restype = C.c_int
+    have = lib.capsyolo_abi_version()
+    if have != ABI_VERSION:     # same symbol names with other argument lists would be called with shifted arguments
+        raise HipExtensionError('%s has ABI version %d, these bindings were written for %d: rebuild it '
+                                '(make -C cs231-capsule-yolo-traffic-sign-detection_amd/csrc)' % (LIB_PATH, have, ABI_VERSION))
     for name, argtypes in _SIGS.items():
         fn = getattr(lib, name)
         fn.argtypes, fn.restype = argtypes, C.c_int
@@ -167,9 +174,14 @@ def load():
     return lib
 
 
+TRACE = None        # a list: every C-ABI call appends its entry-point name (launch census of tests / tools); None = off
+
+
 def call(name, *args):
     """Call an int-returning entry point; non-zero -> HipExtensionError with the library's message."""
     lib = load()
+    if TRACE is not None:
+        TRACE.append(name)
     rc = getattr(lib, name)(*args)
     if rc != 0:
         msg = lib.capsyolo_last_error()

@@ -317,6 +317,31 @@ extern "C" int cy_bn_eval_scale_shift(const float* gamma, const float* beta, con
   return 0;
 }
 
+// Eval-mode BatchNorm folded into the convolution in front of it (predict_fns.py:38-43, 65-69 run models.py:132-223, 347-365 in
+// eval mode): BN(conv(x; W) + b) = conv(x; W') + b' with s = gamma / sqrt(running_var + eps), W'[co] = W[co] s[co],
+// b'[co] = (b[co] - running_mean[co]) s[co] + beta[co].  One thread per weight; thread 0 of each channel writes b'.
+__global__ __launch_bounds__(256) void bn_fold_eval_kernel(const float* __restrict__ W, const float* __restrict__ bias,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           const float* __restrict__ rmean, const float* __restrict__ rvar, float eps,
+                                                           float* __restrict__ Wf, float* __restrict__ bf, int Cout, int per_out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long long)Cout * per_out) return;
+  const int co = (int)(i / per_out);
+  const float sc = gamma[co] / sqrtf(rvar[co] + eps);
+  Wf[i] = W[i] * sc;
+  if (i == (long long)co * per_out) bf[co] = ((bias != nullptr ? bias[co] : 0.f) - rmean[co]) * sc + beta[co];
+}
+
+extern "C" int cy_bn_fold_eval(const float* W, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                               const float* running_var, float eps, float* Wf, float* bf, int Cout, int per_out, void* stream) {
+  CY_REQUIRE(W && gamma && beta && running_mean && running_var && Wf && bf && Cout > 0 && per_out > 0, "cy_bn_fold_eval: bad arguments");
+  const long long n = (long long)Cout * per_out;
+  bn_fold_eval_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(W, bias, gamma, beta, running_mean, running_var,
+                                                                                    eps, Wf, bf, Cout, per_out);
+  CY_LAUNCH_CHECK("cy_bn_fold_eval");
+  return 0;
+}
+
 extern "C" int cy_affine_act(const float* Z, float* A, const float* scale, const float* shift, float slope,
                              long long P, int N, void* stream) {
   CY_REQUIRE(Z && A && P > 0 && N > 0, "cy_affine_act: bad arguments");

@@ -244,6 +244,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
         float v = acc[mi][ni][r] + bv;
         if (a.stats != nullptr && n < a.N && rowoff[wave_m * 64 + row_l] >= 0) { ssum[ni] += v; ssq[ni] += v * v; }
         if (a.act == 1) v = fmaxf(v, 0.f);
+        else if (a.act == 2) v = fmaxf(v, v * a.act_slope);       // LeakyReLU, 0 <= slope <= 1 (eval forward, BatchNorm folded)
         ow[row_l * WC + ni * 32 + li] = v;
       }
     }
@@ -703,6 +704,8 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   CY_REQUIRE(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->N > 0 && a->Cin > 0 && a->TH > 0 && a->TW > 0,
              "cy_conv_gemm: non-positive dimension");
   CY_REQUIRE(a->TH * a->TW <= 4096, "cy_conv_gemm: too many taps");
+  CY_REQUIRE(a->act >= 0 && a->act <= 2 && (a->act != 2 || (a->act_slope >= 0.f && a->act_slope <= 1.f)),
+             "cy_conv_gemm: act=%d / act_slope=%g (LeakyReLU slope must be in [0, 1])", a->act, (double)a->act_slope);
   CY_REQUIRE(a->bn_red == nullptr || (a->bn_z && a->bn_scale && a->bn_shift && a->bn_mean && a->bn_invstd && a->N % 4 == 0 &&
                                       (((uintptr_t)a->Y | (uintptr_t)a->bn_z) & 15) == 0),
              "cy_conv_gemm: bn_red needs bn_z / scale / shift / mean / invstd, N %% 4 == 0 and 16-byte aligned Y, bn_z");

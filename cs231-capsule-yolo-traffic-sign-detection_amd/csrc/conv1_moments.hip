@@ -22,10 +22,18 @@ constexpr int MOM = 32 * 32;                // floats of one partial Gram matrix
 // and every MFMA operand is ONE ds_read_b32.  LDS operations of a wave complete in order: no barrier anywhere in the loop.
 constexpr int SEGW = 32, SEGE = 9 * (SEGW + 2), SEGQ = (SEGE + 63) / 64, SEGB = 320;   // elements, loads per lane, floats per buffer
 
-__global__ __launch_bounds__(256, 1) void conv1_moments_kernel(const float* __restrict__ X, float* __restrict__ part, int B, int H,
+// Exactness: a data-set image is k / 128 with |k| <= 128 (utils.py:122-123), so every product of two taps is a multiple of 2^-14 of
+// magnitude <= 1 and an fp32 accumulator holds the sum of up to 1024 of them EXACTLY (< 2^10 at a granularity of 2^-14: 24 bits).
+// The MFMA accumulators are therefore flushed into per-lane doubles every FLUSH_SEGS segments (16 pixels per accumulator and
+// segment): M2 comes out exact for such images whatever their mean or spatial correlation (bright, smooth images with
+// zero-sum filters make w^T M2 w - (w . m1)^2 / P cancel by three to four digits: an fp32-accumulated M2 would leave 1e-3 of the
+// variance there), and for general float images the fp32 chains are at most 960 terms long.
+constexpr int FLUSH_SEGS = 60;
+
+__global__ __launch_bounds__(256, 1) void conv1_moments_kernel(const float* __restrict__ X, double* __restrict__ part, int B, int H,
                                                               int W) {
   __shared__ float seg[4][2][SEGB];
-  __shared__ float red[4][MOM];
+  __shared__ double red[4][MOM];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int m = lane & 31, k = lane >> 5;
@@ -84,8 +92,13 @@ __global__ __launch_bounds__(256, 1) void conv1_moments_kernel(const float* __re
       if (lane + 64 * q < SEGE) seg[wave][buf][slds[q]] = stg[q];
   };
   f32x16 acc0, acc1;
+  double dacc[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; dacc[r] = 0.0; }
+  auto flush = [&]() {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dacc[r] += (double)acc0[r] + (double)acc1[r]; acc0[r] = 0.f; acc1[r] = 0.f; }
+  };
   // Segment n is consumed from LDS buffer n % 2; its successor is parked right behind its MFMAs, from a register set that was
   // requested THREE segments (~3 k cycles) earlier: every segment touches lines nobody on this CU has read yet.
   const long long nmine = gw < nseg ? (nseg - gw + nw - 1) / nw : 0;
@@ -105,12 +118,15 @@ __global__ __launch_bounds__(256, 1) void conv1_moments_kernel(const float* __re
   if (nmine > 1) request(st1);
   if (nmine > 2) request(st2);
   long long n = 0;
+  int since_flush = 0;
   // steady state, straight-line (6 = 2 LDS buffers x 3 register sets): every request, consume and park of these steps exists
   for (; n + 9 <= nmine; n += 6) {
 #define CY_MOM_STEP(K, REQ, PARK) request(REQ); consume((K) & 1); park(PARK, ((K) + 1) & 1);
     CY_MOM_STEP(0, st0, st1) CY_MOM_STEP(1, st1, st2) CY_MOM_STEP(2, st2, st0)
     CY_MOM_STEP(3, st0, st1) CY_MOM_STEP(4, st1, st2) CY_MOM_STEP(5, st2, st0)
 #undef CY_MOM_STEP
+    since_flush += 6;
+    if (since_flush >= FLUSH_SEGS - 14) { flush(); since_flush = 0; }     // (the guarded tail below adds up to 14 more segments)
   }
   for (; n < nmine; n += 6) {                 // the last steps, guarded
 #define CY_MOM_STEP(K, REQ, PARK)                                              \
@@ -124,18 +140,19 @@ __global__ __launch_bounds__(256, 1) void conv1_moments_kernel(const float* __re
 #undef CY_MOM_STEP
   }
   // D[row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)][col = lane & 31]
+  flush();
 #pragma unroll
-  for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * k) * 32 + m] = acc0[r] + acc1[r];
+  for (int r = 0; r < 16; ++r) red[wave][((r & 3) + 8 * (r >> 2) + 4 * k) * 32 + m] = dacc[r];
   __syncthreads();
   for (int e = t; e < MOM; e += 256) part[(long long)blockIdx.x * MOM + e] = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
 }
 
 // M2[e] = sum over the blocks' partial matrices, in double: block j -> entries 16 j .. 16 j + 15, thread = (entry, partial group)
-__global__ __launch_bounds__(256) void conv1_moments_sum_kernel(const float* __restrict__ part, int nblocks, double* __restrict__ M2) {
+__global__ __launch_bounds__(256) void conv1_moments_sum_kernel(const double* __restrict__ part, int nblocks, double* __restrict__ M2) {
   __shared__ double red[16][17];
   const int e = blockIdx.x * 16 + (threadIdx.x & 15), gsub = threadIdx.x >> 4;
   double s = 0.0;
-  for (int p = gsub; p < nblocks; p += 16) s += (double)part[(long long)p * MOM + e];
+  for (int p = gsub; p < nblocks; p += 16) s += part[(long long)p * MOM + e];
   red[threadIdx.x & 15][gsub] = s;
   __syncthreads();
   if (threadIdx.x < 16) {
@@ -186,7 +203,7 @@ int moments_blocks(long long rows, long long* blocks, const char* who) {
 extern "C" long long cy_conv1_3x3_stats_ws_floats(int B, int H) {
   long long blocks = 0;
   if (B <= 0 || H <= 0 || moments_blocks((long long)B * H, &blocks, "cy_conv1_3x3_stats_ws_floats")) return -1;
-  return blocks * MOM + 2 * MOM;              // the blocks' partial matrices + M2 in double
+  return 2 * blocks * MOM + 2 * MOM;          // the blocks' partial matrices and M2, all in double
 }
 
 // float offset of the double M2[32][32] (row 27 = sum patch, [27][27] = pixel count) inside ws after cy_conv1_3x3_stats: the one-pass
@@ -194,7 +211,7 @@ extern "C" long long cy_conv1_3x3_stats_ws_floats(int B, int H) {
 extern "C" long long cy_conv1_3x3_stats_m2_offset(int B, int H) {
   long long blocks = 0;
   if (B <= 0 || H <= 0 || moments_blocks((long long)B * H, &blocks, "cy_conv1_3x3_stats_m2_offset")) return -1;
-  return blocks * MOM;
+  return 2 * blocks * MOM;
 }
 
 extern "C" int cy_conv1_3x3_stats(const float* X, const float* W, const float* bias, double* stats, float* ws, int B, int H, int Wd,
@@ -207,10 +224,10 @@ extern "C" int cy_conv1_3x3_stats(const float* X, const float* W, const float* b
   int rc = moments_blocks((long long)B * H, &blocks, "cy_conv1_3x3_stats");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  double* M2 = (double*)(ws + blocks * MOM);
-  conv1_moments_kernel<<<(unsigned)blocks, 256, 0, s>>>(X, ws, B, H, Wd);
+  double* M2 = (double*)(ws + 2 * blocks * MOM);
+  conv1_moments_kernel<<<(unsigned)blocks, 256, 0, s>>>(X, (double*)ws, B, H, Wd);
   CY_LAUNCH_CHECK("cy_conv1_3x3_stats(moments)");
-  conv1_moments_sum_kernel<<<MOM / 16, 256, 0, s>>>(ws, (int)blocks, M2);
+  conv1_moments_sum_kernel<<<MOM / 16, 256, 0, s>>>((const double*)ws, (int)blocks, M2);
   CY_LAUNCH_CHECK("cy_conv1_3x3_stats(sum)");
   conv1_moments_stats_kernel<<<(Cout + 63) / 64, 256, 0, s>>>(M2, W, bias, stats, Cout);
   CY_LAUNCH_CHECK("cy_conv1_3x3_stats(stats)");

@@ -56,6 +56,7 @@ __device__ __attribute__((aligned(16))) unsigned conv_bf16_zero16[4];
 struct Geo {
   const u16* X; const u16* Wp; void* Y; const float* bias; double* stats;
   int B, Hi, Wi, Cin, Ho, Wo, N, TH, TW, in_stride, dy0, dx0, dstep, Hy, Wy, out_stride, out_oy, out_ox, act;
+  float act_slope;                                  // act == 2: LeakyReLU slope (eval forward, BatchNorm folded into the weights)
   long long M;                                      // B * Ho * Wo
   int K;                                            // TH * TW * Cin
   int ntm, ntn;                                     // tiles along M and N
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    const bool relu = a.act == 1, has_stats = a.stats != nullptr;
+    const bool relu = a.act != 0, has_stats = a.stats != nullptr;
+    const float act_lo = a.act == 2 ? a.act_slope : 0.f;          // max(v, v * act_lo): ReLU (0) or LeakyReLU (0 <= slope <= 1)
     long long pf0 = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0, pfw = 0, pfv = 0;
     for (int kt = 0; kt < KT; ++kt) {
       const long long pfa = a.prof ? (long long)__builtin_amdgcn_s_memtime() : 0;
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
               float v = acc[mi][ni][8 * hf + r8] + bvv[ni];
               const float vs = v * (okf[r8] * nok);
               ssum[ni] += vs; ssq[ni] = __builtin_fmaf(vs, vs, ssq[ni]);
-              if (relu) v = fmaxf(v, 0.f);
+              if (relu) v = fmaxf(v, v * act_lo);
               ow[row_l * WC + ni * 32 + li] = v;
             }
           }
@@ -305,7 +307,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
             for (int r8 = 0; r8 < 8; ++r8) {
               const int row_l = (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;         // 0 .. 15
               float v = acc[mi][ni][8 * hf + r8] + bvv[ni];
-              if (relu) v = fmaxf(v, 0.f);
+              if (relu) v = fmaxf(v, v * act_lo);
               ow[row_l * WC + ni * 32 + li] = v;
             }
           }
@@ -481,7 +483,9 @@ extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* str
   g.X = (const u16*)a->X; g.Wp = (const u16*)a->Wp; g.Y = (void*)a->Y; g.bias = a->bias; g.stats = a->stats;
   g.B = a->B; g.Hi = a->Hi; g.Wi = a->Wi; g.Cin = a->Cin; g.Ho = a->Ho; g.Wo = a->Wo; g.N = a->N; g.TH = a->TH; g.TW = a->TW;
   g.in_stride = a->in_stride; g.dy0 = a->dy0; g.dx0 = a->dx0; g.dstep = a->dstep; g.Hy = a->Hy; g.Wy = a->Wy;
-  g.out_stride = a->out_stride; g.out_oy = a->out_oy; g.out_ox = a->out_ox; g.act = a->act;
+  g.out_stride = a->out_stride; g.out_oy = a->out_oy; g.out_ox = a->out_ox; g.act = a->act; g.act_slope = a->act_slope;
+  CY_REQUIRE(a->act >= 0 && a->act <= 2 && (a->act != 2 || (a->act_slope >= 0.f && a->act_slope <= 1.f)),
+             "cy_conv_gemm_bf16: act=%d / act_slope=%g (LeakyReLU slope must be in [0, 1])", a->act, (double)a->act_slope);
   g.M = (long long)a->B * a->Ho * a->Wo;
   CY_REQUIRE(g.M < (1ll << 31) - 512, "cy_conv_gemm_bf16: more than 2^31 output pixels");
   g.K = a->TH * a->TW * a->Cin;

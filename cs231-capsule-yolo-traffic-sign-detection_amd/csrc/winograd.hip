@@ -48,6 +48,7 @@ struct WinoArgs {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
   int B, H, W, Cin, Cout, Np, tbh, tbw;
   int ntiles;                               // B * tbh * tbw * Np/64 output tiles, walked by a persistent grid
+  float out_slope;                          // EPI == 2: Y = lrelu(conv + bias) with this slope (eval mode, BatchNorm folded into U / bias)
 };
 
 __device__ __forceinline__ f32x16 mfma_zero() {
@@ -188,10 +189,12 @@ constexpr int wino_younger(int xi) {
   return n > 14 ? 14 : n;
 }
 
-// STATS: BatchNorm statistics from the epilogue (a kernel-level variant: the test inside the accumulator rows was a uniform
-// branch per row, ~40 cycles each on a wave that is alone on its SIMD)
-template <bool STATS>
+// EPI: epilogue variant at kernel level (a test inside the accumulator rows was a uniform branch per row, ~40 cycles each on a
+// wave that is alone on its SIMD): 0 plain (input gradient), 1 BatchNorm statistics (training forward), 2 LeakyReLU (eval
+// forward with the BatchNorm folded into weights and bias: models.py:349-351 in eval mode is conv' -> LeakyReLU)
+template <int EPI>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
+  constexpr bool STATS = EPI == 1;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][VU_BUF]
   float* Us = smem + 2 * VU_BUF;            // [2][VU_BUF]
@@ -479,8 +482,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
         s0[j] = m0 + m1 + m2;
         s1[j] = m1 - m2 - m3;
       }
-      const float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
-      const float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+      float y00 = s0[0] + s0[1] + s0[2] + bv, y01 = s0[1] - s0[2] - s0[3] + bv;
+      float y10 = s1[0] + s1[1] + s1[2] + bv, y11 = s1[1] - s1[2] - s1[3] + bv;
+      if constexpr (EPI == 2) {             // 0 <= slope <= 1 (checked on the host): lrelu(y) = max(y, slope y)
+        y00 = fmaxf(y00, y00 * a.out_slope); y01 = fmaxf(y01, y01 * a.out_slope);
+        y10 = fmaxf(y10, y10 * a.out_slope); y11 = fmaxf(y11, y11 * a.out_slope);
+      }
       float* op = ow + tloc * 128 + li;
       op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
       if constexpr (has_stats) {
@@ -1139,16 +1146,18 @@ extern "C" int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin,
   return 0;
 }
 
-extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, int B, int H,
-                                   int W, int Cin, int Cout, void* stream) {
+extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
+                                   int B, int H, int W, int Cin, int Cout, void* stream) {
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv3x3_winograd: bad arguments");
+  CY_REQUIRE(out_slope >= 0.f && out_slope <= 1.f, "cy_conv3x3_winograd: out_slope=%g must be in [0, 1] (1 = no activation)", (double)out_slope);
+  CY_REQUIRE(out_slope == 1.f || stats == nullptr, "cy_conv3x3_winograd: the activation epilogue is for eval-mode forwards (no statistics)");
   CY_REQUIRE(Cin % KC == 0 && Cin >= KC, "cy_conv3x3_winograd: Cin=%d must be a multiple of %d", Cin, KC);
   CY_REQUIRE(Cin <= WINO_MAX_CIN, "cy_conv3x3_winograd: Cin=%d exceeds %d", Cin, WINO_MAX_CIN);
   CY_REQUIRE((((uintptr_t)X | (uintptr_t)U) & 15) == 0, "cy_conv3x3_winograd: operands must be 16-byte aligned");
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29) && (long long)H * W * Cout < (1ll << 29),
              "cy_conv3x3_winograd: image too large for 32-bit byte offsets");
   WinoArgs a;
-  a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
+  a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats; a.out_slope = out_slope;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.Np = (Cout + 63) / 64 * 64;
   a.tbh = (H + 15) / 16; a.tbw = (W + 15) / 16;
@@ -1161,12 +1170,15 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "cy_conv3x3_winograd: cannot query the CU count: %s", hipGetErrorString(he));
   const long long blocks = tiles < ncu ? tiles : ncu;   // persistent: one block per CU (155 KB of LDS, 512 registers per lane)
   const size_t lds = (size_t)(4 * VU_BUF + 2 * RAW_BUF) * 4;
-  int rc = cy_allow_lds(wino_conv_kernel<true>, lds);
+  int rc = cy_allow_lds(wino_conv_kernel<1>, lds);
   if (rc) return rc;
-  rc = cy_allow_lds(wino_conv_kernel<false>, lds);
+  rc = cy_allow_lds(wino_conv_kernel<0>, lds);
   if (rc) return rc;
-  if (a.stats != nullptr) wino_conv_kernel<true><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
-  else wino_conv_kernel<false><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  rc = cy_allow_lds(wino_conv_kernel<2>, lds);
+  if (rc) return rc;
+  if (a.stats != nullptr) wino_conv_kernel<1><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else if (out_slope != 1.f) wino_conv_kernel<2><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else wino_conv_kernel<0><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd");
   return 0;
 }

@@ -65,6 +65,7 @@ struct Wino2Args {
   int Hx, Wx, Cx;
   const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
   double* bn_red; float bn_slope;
+  float out_slope;                          // ACT (forward, eval mode): Y = lrelu(conv + bias) with this slope, BatchNorm folded into U / bias
 };
 
 // 18 accumulator tiles = 288 registers, the AGPR file has 256: left to itself the compiler shuttles accumulators
@@ -156,7 +157,7 @@ constexpr int s2_younger(int xi) {
 // tensor dY shifted by one pixel, with K = Cout of the layer (chunks of 8 output channels) and N = 4 Cin; the epilogue
 // scatters element (Y, X, q = (py, px, c)) to dX(2Y - 1 + py, 2X - 1 + px, c).
 // AFFINE: the input is lrelu(X * in_scale[c] + in_shift[c]) (forward only), applied on the way from registers to LDS.
-template <int MODE, bool AFFINE>
+template <int MODE, bool AFFINE, bool ACT = false>
 __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Vs = smem;                         // [2][V2_BUF]
@@ -628,8 +629,12 @@ __global__ __launch_bounds__(256, 1) void wino2_conv_kernel(Wino2Args a) {
 #pragma unroll
       for (int xi = 0; xi < 8; ++xi) m[xi] = acc_elem(acc[xi][mi][r]);
       m[8] = acc[8][mi][r];
-      const float y00 = (m[0] + m[1]) + (m[3] + m[4]) + bv, y01 = (m[1] + m[2]) + (m[4] + m[5]) + bv;
-      const float y10 = (m[3] + m[4]) + (m[6] + m[7]) + bv, y11 = (m[4] + m[5]) + (m[7] + m[8]) + bv;
+      float y00 = (m[0] + m[1]) + (m[3] + m[4]) + bv, y01 = (m[1] + m[2]) + (m[4] + m[5]) + bv;
+      float y10 = (m[3] + m[4]) + (m[6] + m[7]) + bv, y11 = (m[4] + m[5]) + (m[7] + m[8]) + bv;
+      if constexpr (ACT) {                  // 0 <= slope <= 1 (checked on the host): lrelu(y) = max(y, slope y)
+        y00 = fmaxf(y00, y00 * a.out_slope); y01 = fmaxf(y01, y01 * a.out_slope);
+        y10 = fmaxf(y10, y10 * a.out_slope); y11 = fmaxf(y11, y11 * a.out_slope);
+      }
       float* op = ow + tloc * 128 + li;
       op[0] = y00; op[32] = y01; op[64] = y10; op[96] = y11;
       if (has_stats) {
@@ -1136,8 +1141,11 @@ static int wino2_persistent_blocks(long long tiles, long long* blocks, const cha
 }
 
 extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
-                                     const float* in_scale, const float* in_shift, float in_slope, int B, int H,
+                                     const float* in_scale, const float* in_shift, float in_slope, float out_slope, int B, int H,
                                      int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE(out_slope >= 0.f && out_slope <= 1.f, "cy_conv4x4s2_winograd: out_slope=%g must be in [0, 1] (1 = no activation)", (double)out_slope);
+  CY_REQUIRE(out_slope == 1.f || (stats == nullptr && in_scale == nullptr),
+             "cy_conv4x4s2_winograd: the activation epilogue is for eval-mode forwards (no statistics, no fused input affine)");
   CY_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "cy_conv4x4s2_winograd: in_scale and in_shift go together");
   CY_REQUIRE(in_scale == nullptr || (in_slope > 0.f && in_slope <= 1.f), "cy_conv4x4s2_winograd: in_slope must be in (0, 1]");
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv4x4s2_winograd: bad arguments");
@@ -1147,7 +1155,7 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   CY_REQUIRE((long long)H * W * Cin < (1ll << 29), "cy_conv4x4s2_winograd: image too large for 32-bit offsets");
   Wino2Args a;
   a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats;
-  a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_slope = in_slope; a.out_slope = out_slope;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
   a.Np = (Cout + 63) / 64 * 64;
   a.Ho = H / 2; a.Wo = W / 2;
@@ -1165,9 +1173,11 @@ extern "C" int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, c
   if (const char* e = getenv("CY_W2_PROF")) a.bn_red = (double*)strtoull(e, nullptr, 0);
   if (const char* e = getenv("CY_W2_STAMPS")) a.bn_scale = (const float*)strtoull(e, nullptr, 0);
 #endif
-  int rc = in_scale ? cy_allow_lds(wino2_conv_kernel<0, true>, lds) : cy_allow_lds(wino2_conv_kernel<0, false>, lds);
+  int rc = in_scale ? cy_allow_lds(wino2_conv_kernel<0, true>, lds)
+                    : out_slope != 1.f ? cy_allow_lds(wino2_conv_kernel<0, false, true>, lds) : cy_allow_lds(wino2_conv_kernel<0, false>, lds);
   if (rc) return rc;
   if (in_scale) wino2_conv_kernel<0, true><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else if (out_slope != 1.f) wino2_conv_kernel<0, false, true><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   else wino2_conv_kernel<0, false><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd");
   return 0;
@@ -1241,7 +1251,7 @@ extern "C" int cy_conv4x4s2_winograd_dgrad(const float* dZ, const float* U, floa
 #ifdef W2_PROF
   if (const char* e = getenv("CY_W2_PROF")) a.bias = (const float*)strtoull(e, nullptr, 0);
 #endif
-  a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f;
+  a.in_scale = a.in_shift = nullptr; a.in_slope = 1.f; a.out_slope = 1.f;
 #ifdef W2_PROF
   if (getenv("CY_W2_NOSTORE")) a.in_slope = 2.f;
 #endif

@@ -14,14 +14,26 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world > 1 and not dist.is_initialized():
-        if backend is None:
-            backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        if backend is None:       # CAPSYOLO_DP_BACKEND=gloo: rehearse the N>1 path on fewer GPUs than ranks
+            backend = os.environ.get('CAPSYOLO_DP_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend == 'nccl':
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_device_index(local_rank, backend))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local_rank
+
+
+def local_device_index(local_rank, backend='nccl'):
+    """The GPU of this rank.  RCCL wants one GPU per rank: a local rank without a device of its own is an error there.
+    Under 'gloo' (rehearsals of the N>1 code path on a box with fewer GPUs than ranks, tests) ranks may share a device."""
+    n = torch.cuda.device_count()
+    if n == 0 or local_rank < n:
+        return local_rank
+    if backend == 'nccl':
+        raise RuntimeError('local rank %d has no GPU of its own (%d visible): backend nccl (RCCL) needs one GPU per rank; '
+                           'use backend gloo to rehearse on shared devices' % (local_rank, n))
+    return local_rank % n
 
 
 def world_size():

@@ -74,6 +74,12 @@ class FusedBackbone(nn.Sequential):
         runs on v_mfma_f32_32x32x16_bf16 with bf16 activations, fp32 accumulation and fp32 / double statistics; the
         last block hands its activation over in fp32 (the routing head is an fp32 kernel)."""
         names, mods = zip(*self.named_children())
+        for nm, m in zip(names, mods):
+            # this walk only knows conv -> BatchNorm -> LeakyReLU triples: any other child (max-pool, dropout with p > 0)
+            # would be skipped silently and a DIFFERENT network computed
+            if not (isinstance(m, (HipConv2d, HipBatchNorm2d, HipLeakyReLU)) or (isinstance(m, nn.Dropout) and m.p == 0)):
+                raise ops._lib.HipExtensionError('precision bf16: child %s (%s) has no bf16 path; the bf16 backbone is built '
+                                                 'for conv -> BatchNorm -> LeakyReLU blocks only' % (nm, type(m).__name__))
         convs = [i for i, m in enumerate(mods) if isinstance(m, HipConv2d)]
         first = True
         for n, i in enumerate(convs):
@@ -115,7 +121,7 @@ class FusedBackbone(nn.Sequential):
                 # Winograd forward and weight-gradient kernels apply BatchNorm + LeakyReLU on their loads: the
                 # activation tensor (5.7 GB after conv_2 at the headline shape) is never written
                 defer = False
-                if (ops.FUSE_INPUT_AFFINE and bn is not None and slope is not None and 0.0 < slope <= 1.0
+                if (ops.FUSE_INPUT_AFFINE and self.training and bn is not None and slope is not None and 0.0 < slope <= 1.0
                         and nxt < len(mods) and isinstance(mods[nxt], HipConv2d)):
                     n = mods[nxt]
                     hin = x.shape[2] if nchw_in else x.shape[1]

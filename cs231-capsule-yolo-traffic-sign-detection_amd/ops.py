@@ -152,8 +152,9 @@ def _winograd_ok(k, stride, pad, cin, nchw):
     return USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and not nchw and cin % 8 == 0 and cin >= 8
 
 
-def _winograd(x, weight, bias, stats, transpose, tag):
-    """x [B,H,W,Cg] NHWC; weight in PyTorch layout; transpose=True computes the input gradient of the layer."""
+def _winograd(x, weight, bias, stats, transpose, tag, out_slope=1.0):
+    """x [B,H,W,Cg] NHWC; weight in PyTorch layout; transpose=True computes the input gradient of the layer.
+    out_slope != 1: LeakyReLU epilogue (eval forward with the BatchNorm folded into weight / bias)."""
     B, H, W_, Cg = x.shape
     Cout_l, Cin_l = weight.shape[0], weight.shape[1]
     n = Cin_l if transpose else Cout_l
@@ -162,7 +163,7 @@ def _winograd(x, weight, bias, stats, transpose, tag):
     call('cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
     y = _empty((B, H, W_, n), x)
     with timer.range(('conv_wino_dgrad/' if transpose else 'conv_wino_fwd/') + tag):
-        call('cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), B, H, W_, Cg, n, st)
+        call('cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), float(out_slope), B, H, W_, Cg, n, st)
     return y
 
 
@@ -190,8 +191,13 @@ def conv1_affine_act(x, weight, bias, scale, shift, slope, tag='conv', out_bf16=
     return out
 
 
-def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv', in_affine=None):
-    """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output."""
+def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=False, tag='conv', in_affine=None, lrelu=None):
+    """z[B,Ho,Wo,Cout] = conv2d(x) (+bias, optional fused ReLU); optional BN statistics side output.
+    lrelu = slope in [0, 1]: LeakyReLU epilogue (the eval-mode forward of a block whose BatchNorm is folded into weight / bias)."""
+    if lrelu is not None and (relu or stats is not None or in_affine is not None or not 0.0 <= lrelu <= 1.0):
+        raise _lib.HipExtensionError('conv_forward: the LeakyReLU epilogue (slope %r) is the eval-mode forward: no statistics, no '
+                                     'fused input affine, slope in [0, 1]' % (lrelu,))
+    osl = 1.0 if lrelu is None else float(lrelu)
     x, weight = _f32(x, 'conv input'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     Cout = weight.shape[0]
@@ -200,7 +206,7 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
         raise _lib.HipExtensionError('a fused input affine needs the 4x4/stride-2 Winograd kernels (got k=%d s=%d Cin=%d Cout=%d)'
                                      % (k, stride, Cin, Cout))
     if not relu and _winograd_ok(k, stride, pad, Cin, nchw):
-        return _winograd(x, weight, bias, stats, False, tag)
+        return _winograd(x, weight, bias, stats, False, tag, osl)
     if (USE_WINOGRAD and USE_WINOGRAD_S2 and not relu and k == 4 and stride == 2 and pad == 1 and not nchw
             and Cin % 8 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and x.is_contiguous()):
         st = _stream()
@@ -210,9 +216,9 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
         isc, ish, isl = in_affine if in_affine is not None else (None, None, 1.0)
         with timer.range('conv_wino2_fwd/' + tag):
             call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
-                 float(isl), B, Hi, Wi, Cin, Cout, st)
+                 float(isl), osl, B, Hi, Wi, Cin, Cout, st)
         return y
-    if not relu and conv1_ok(x, weight, k, stride, pad, nchw):
+    if not relu and lrelu is None and conv1_ok(x, weight, k, stride, pad, nchw):
         # the backbones' first layer (store-bound): persistent waves, operands from registers / L2
         st = _stream()
         z = _empty((B, Ho, Wo, Cout), x)
@@ -229,7 +235,7 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
                  stats=stats.data_ptr() if stats is not None else None,
                  xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                  TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1,
-                 Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=1 if relu else 0)
+                 Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=1 if relu else 2 if lrelu is not None else 0, act_slope=osl)
     with timer.range('conv_gemm_fwd/' + tag):
         call('cy_conv_gemm', C.byref(a), st)
     return z
@@ -346,6 +352,32 @@ def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv', in_affine=None):
     return dW
 
 
+FOLD_EVAL_BN = True   # eval mode: the BatchNorm is folded into weights / bias once and the block's forward is conv + LeakyReLU epilogue
+PARAM_EPOCH = 0       # bumped by everything that writes parameters / running statistics through raw pointers (optim.Adam.step,
+                      # cy_bn_finalize in a training forward): part of the fold cache's key next to the tensors' version counters
+
+
+def _bump_param_epoch():
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+
+
+def fold_eval_bn(weight, bias, gamma, beta, bn):
+    """(W', b') of the eval-mode block: W'[co] = W[co] * s[co], b' = (b - running_mean) * s + beta, s = gamma / sqrt(running_var
+    + eps) (cy_bn_fold_eval), cached on the BatchNorm module until a parameter or running statistic changes."""
+    ts = (weight, bias, gamma, beta, bn.running_mean, bn.running_var)
+    key = (PARAM_EPOCH, float(bn.eps)) + tuple((t.data_ptr(), t._version) if t is not None else None for t in ts)
+    hit = getattr(bn, '_cy_fold', None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    weight = _f32(weight, 'conv weight')
+    Wf, bf = torch.empty_like(weight), _empty((weight.shape[0],), weight)
+    call('cy_bn_fold_eval', _ptr(weight), _ptr(bias), _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
+         float(bn.eps), _ptr(Wf), _ptr(bf), weight.shape[0], weight.numel() // weight.shape[0], _stream())
+    bn._cy_fold = (key, Wf, bf)
+    return Wf, bf
+
+
 class ConvBlockCfg(object):
     """Static description of one conv (+BatchNorm) (+activation) block."""
 
@@ -431,7 +463,25 @@ class _ConvBlock(torch.autograd.Function):
                  _ptr(bn.running_var), float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean),
                  _ptr(invstd), N, _ptr(bn.num_batches_tracked), st)
             ctx.bn_train = True
+            _bump_param_epoch()               # running statistics were written through raw pointers
         else:
+            ctx.folded = False
+            if FOLD_EVAL_BN and not cfg.defer_act and ina is None and 0.0 <= slope <= 1.0:
+                # eval mode (predict_fns.py:38-43, 65-69): ONE launch per block.  The first layer applies scale / shift in its
+                # own epilogue (its kernel takes them); every other layer runs on weights and bias with the BatchNorm folded in
+                ctx.folded = True
+                ctx.save_for_backward()
+                if conv1_ok(x, weight, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in):
+                    call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
+                         float(bn.eps), _ptr(scale), _ptr(shift), N, st)
+                    return conv1_affine_act(x, weight, bias, scale, shift, slope, cfg.name, bool(getattr(cfg, 'out_bf16', False)))
+                Wf, bf = fold_eval_bn(weight, bias, gamma, beta, bn)
+                out = conv_forward(x, Wf, bf, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False, cfg.name, None, lrelu=slope)
+                if getattr(cfg, 'out_bf16', False):
+                    ob = torch.empty(out.shape, dtype=torch.bfloat16, device=out.device)
+                    call('cy_cast_f32_bf16', _ptr(out), _ptr(ob), out.numel(), st)
+                    return ob
+                return out
             z = conv_forward(x, weight, bias, cfg.k, cfg.stride, cfg.pad, cfg.nchw_in, None, False, cfg.name, ina)
             P = z.numel() // N
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
@@ -461,6 +511,8 @@ class _ConvBlock(torch.autograd.Function):
         cfg = ctx.cfg
         if da is None:
             raise _lib.HipExtensionError('conv block %s: no gradient reached its output' % cfg.name)
+        if getattr(ctx, 'folded', False):
+            raise _lib.HipExtensionError('backward through an eval-mode BatchNorm block is not implemented')
         da_bf16 = da.dtype == torch.bfloat16 and bool(getattr(cfg, 'out_bf16', False))
         if da_bf16 and not (cfg.bn is not None and ctx.bn_train and ctx.conv1_fused):
             daf = torch.empty(da.shape, dtype=torch.float32, device=da.device)   # only the first-layer kernels read a bf16 gradient
@@ -620,8 +672,9 @@ class _CastBF16(torch.autograd.Function):
         return dy
 
 
-def conv_forward_bf16(x, weight, bias, k, stride, pad, stats=None, tag='conv'):
-    """z (bf16 NHWC) = conv2d(x bf16 NHWC) + bias with fp32 accumulation; optional BatchNorm statistics."""
+def conv_forward_bf16(x, weight, bias, k, stride, pad, stats=None, tag='conv', lrelu=None, out_f32=False):
+    """z (bf16 NHWC) = conv2d(x bf16 NHWC) + bias with fp32 accumulation; optional BatchNorm statistics.
+    lrelu = slope in [0, 1]: LeakyReLU epilogue (eval forward, BatchNorm folded into weight / bias); out_f32: fp32 output."""
     x, weight = _bf(x, 'conv input'), _f32(weight, 'conv weight')
     B, Hi, Wi, Cin = x.shape
     Cout = weight.shape[0]
@@ -629,13 +682,14 @@ def conv_forward_bf16(x, weight, bias, k, stride, pad, stats=None, tag='conv'):
     st = _stream()
     wp = torch.empty((query('cy_conv_bf16_packed_elems', k * k * Cin, Cout),), dtype=torch.bfloat16, device=x.device)
     call('cy_conv_bf16_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, k, k, 0, 0, 1, 0, st)
-    z = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=x.device)
+    z = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     a = ConvGemm(X=x.data_ptr(), Wp=wp.data_ptr(), Y=z.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
                  stats=stats.data_ptr() if stats is not None else None,
                  xs_b=Hi * Wi * Cin, xs_y=Wi * Cin, xs_x=Cin, xs_c=1, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
-                 TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1, Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=0)
+                 TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1, Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0,
+                 act=0 if lrelu is None else 2, act_slope=1.0 if lrelu is None else float(lrelu))
     with timer.range('conv_bf16_fwd/' + tag):
-        call('cy_conv_gemm_bf16', C.byref(a), 0, st)
+        call('cy_conv_gemm_bf16', C.byref(a), 1 if out_f32 else 0, st)
     return z
 
 
@@ -707,7 +761,14 @@ class _ConvBlockBF16(torch.autograd.Function):
             call('cy_bn_finalize', _ptr(stats), P * world, _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var),
                  float(bn.momentum), float(bn.eps), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd), N,
                  _ptr(bn.num_batches_tracked), st)
+            _bump_param_epoch()
         else:
+            if FOLD_EVAL_BN and 0.0 <= float(cfg.slope) <= 1.0:     # eval mode: ONE launch, BatchNorm folded into weights / bias
+                Wf, bf = fold_eval_bn(weight, bias, gamma, beta, bn)
+                ctx.bn_train = False
+                ctx.save_for_backward()
+                return conv_forward_bf16(x, Wf, bf, cfg.k, cfg.stride, cfg.pad, None, cfg.name, lrelu=float(cfg.slope),
+                                         out_f32=bool(getattr(cfg, 'out_f32', False)))
             z = conv_forward_bf16(x, weight, bias, cfg.k, cfg.stride, cfg.pad, None, cfg.name)
             P = z.numel() // N
             call('cy_bn_eval_scale_shift', _ptr(gamma), _ptr(beta), _ptr(bn.running_mean), _ptr(bn.running_var), float(bn.eps),

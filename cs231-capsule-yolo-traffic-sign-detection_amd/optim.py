@@ -6,6 +6,7 @@ import ctypes as C
 import numpy as np
 import torch
 
+from . import ops as _ops
 from ._lib import call
 
 _CHUNK = 16384
@@ -76,4 +77,5 @@ class Adam(torch.optim.Optimizer):
             call('cy_adam_multi', C.c_void_p(table.data_ptr()), C.c_void_p(bm.data_ptr()), nblocks, _CHUNK,
                  float(group['lr']), float(b1), float(b2), float(group['eps']), float(1.0 - b1 ** t),
                  float(1.0 - b2 ** t), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+            _ops._bump_param_epoch()          # parameters changed through raw pointers: eval-mode fold caches are stale
         return loss

@@ -45,7 +45,7 @@ typedef struct {
   int Ho, Wo, N;
   int TH, TW, in_stride, dy0, dx0, dstep;
   int Hy, Wy, out_stride, out_oy, out_ox;
-  int act;            /* 0 none, 1 ReLU */
+  int act;            /* 0 none, 1 ReLU, 2 LeakyReLU with slope act_slope (last field) */
   /* Optional (input-gradient launches): Y is the gradient with respect to lrelu(bn_z * bn_scale + bn_shift), the
    * activated output of the PRODUCER block whose raw convolution output bn_z has Y's layout.  The epilogue then also
    * accumulates that BatchNorm's backward sums over the pixels it stores -- per channel n:
@@ -55,6 +55,8 @@ typedef struct {
   const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
   double* bn_red;
   float bn_slope;
+  float act_slope;    /* act == 2: Y = max(v, act_slope * v), 0 <= act_slope <= 1 -- the eval-mode forward of a conv -> BatchNorm ->
+                       * LeakyReLU block whose BatchNorm was folded into weights and bias (cy_bn_fold_eval) */
 } cy_conv_gemm_t;
 
 /* First layer of the backbones (models.py:347-349 DarkCapsuleNet conv_1 3 -> 128, models.py:132-136 DarkNet conv_1
@@ -150,7 +152,7 @@ int cy_conv_wgrad(const cy_conv_wgrad_t* a, void* stream);
  * bias / stats as in cy_conv_gemm (either may be NULL). */
 long long cy_wino_packed_floats(int Cin, int N);
 int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
-int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
+int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
                         int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through Winograd F(3x3,2x2): dW[Cout][Cin][3][3] from X[B][H][W][Cin] and
  * dZ[B][H][W][Cout] (replaces the weight-gradient half of nn.Conv2d backward, models.py:132-223 conv_2 class of
@@ -181,8 +183,10 @@ int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* str
 /* in_scale / in_shift [Cin] (both or neither) + in_slope in (0, 1]: the layer's input is lrelu(X * in_scale[c] + in_shift[c])
  * -- the producer's BatchNorm + LeakyReLU (models.py:349-351) applied on the way into LDS, so that the activation tensor
  * of the previous layer is never written to HBM (X is then the previous layer's raw convolution output). */
+/* out_slope in [0, 1] (1 = none): Y = lrelu(conv + bias) -- the eval-mode forward with the block's BatchNorm folded into U and
+ * bias (cy_bn_fold_eval); then stats and in_scale must be NULL.  cy_conv3x3_winograd takes the same argument. */
 int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
-                          const float* in_scale, const float* in_shift, float in_slope,
+                          const float* in_scale, const float* in_shift, float in_slope, float out_slope,
                           int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through F(2x2,2x2): dW[Cout][Cin][4][4] from X[B][H][W][Cin] and
  * dZ[B][H/2][W/2][Cout].  Cin % 32 == 0, Cout % 64 == 0, H and W even.  ws: cy_wino2_wgrad_ws_floats(B, Cin, Cout) floats
@@ -246,6 +250,12 @@ int cy_bn_red_fold(const double* red_copies, int copies, double scale, double* r
 /* eval mode: scale/shift from the running statistics */
 int cy_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, float eps, float* scale, float* shift, int N, void* stream);
+/* eval mode: the BatchNorm FOLDED into the convolution in front of it (the eval forward of predict_fns.py:38-43, 65-69 over
+ * models.py:132-223, 347-365): Wf[co][...] = W[co][...] * s[co], bf[co] = (bias[co] - running_mean[co]) * s[co] + beta[co] with
+ * s = gamma / sqrt(running_var + eps); W is any [Cout][per_out] weight tensor (PyTorch layout), bias may be NULL.  The block's
+ * eval forward is then ONE launch: the conv kernel on (Wf, bf) with its LeakyReLU epilogue (out_slope / act = 2). */
+int cy_bn_fold_eval(const float* W, const float* bias, const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, float eps, float* Wf, float* bf, int Cout, int per_out, void* stream);
 /* A = lrelu(Z*scale + shift), negative slope `slope` (1.0 = identity, 0.0 = ReLU); scale/shift may be NULL */
 int cy_affine_act(const float* Z, float* A, const float* scale, const float* shift, float slope,
                   long long P, int N, void* stream);

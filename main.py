@@ -176,7 +176,7 @@ def train(x, y, model, optimizer, loss_fn, metric, params, bucket, if_eval=True)
         y_hat_bch, loss = _forward(model, loss_fn, x_bch, y_bch, params)
         if want_metric:
             y_hat.append(y_hat_bch.detach())
-            y_true.append(y_bch)
+            y_true.append(y_bch.detach().clone())        # the feeder's slot buffers are overwritten by later batches
         optimizer.zero_grad()
         loss.backward()
         bucket.allreduce_mean()
@@ -309,7 +309,8 @@ def main(argv=None):
         from capsyolo_amd import ops as _ops
         _ops.SYNC_BN = True
     if params.device == 'cuda':
-        torch.cuda.set_device(local_rank)
+        import torch.distributed as dist
+        torch.cuda.set_device(dp.local_device_index(local_rank, dist.get_backend() if dist.is_initialized() else 'nccl'))
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
     if params.device == 'cuda':

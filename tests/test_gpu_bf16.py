@@ -258,3 +258,41 @@ def test_bf16_rejects_unsupported_blocks():
     with pytest.raises(ValueError):
         models.DarkCapsuleNet(p2)
     assert issubclass(_lib.HipExtensionError, RuntimeError)
+
+
+def test_bf16_eval_forward_folds_batchnorm():
+    """Eval mode on the bf16 path: every block behind the first is ONE bf16 GEMM launch on weights / bias with the BatchNorm
+    folded in (cy_bn_fold_eval -> fp32 masters -> bf16 pack) and a LeakyReLU epilogue; against the unfolded bf16 path (same
+    kernels + cy_affine_act_bf16) within two bf16 roundings, and against the fp32 eval forward at the bf16 tolerance."""
+    from capsyolo_amd import _lib, models, ops
+    H, g, B = 96, 3, 4
+    p = make_params(model='darkcapsule', n_grid=g, darknet_input=H, recon=False, device='cuda', precision='bf16')
+    p32 = make_params(model='darkcapsule', n_grid=g, darknet_input=H, recon=False, device='cuda')
+    torch.manual_seed(0)
+    net = models.DarkCapsuleNet(p).cuda()
+    x = T(synth_images(B, H, seed=43)).cuda()
+    net.train()
+    with torch.no_grad():
+        for _ in range(3):                  # running statistics that are not the initial (0, 1)
+            net(x)
+    net32 = models.DarkCapsuleNet(p32).cuda()
+    net32.load_state_dict(net.state_dict())
+    net.eval(); net32.eval()
+    with torch.no_grad():
+        _lib.TRACE = []
+        try:
+            out = net(x)
+            torch.cuda.synchronize()
+            calls = list(_lib.TRACE)
+        finally:
+            _lib.TRACE = None
+        ops.FOLD_EVAL_BN = False
+        try:
+            out0 = net(x)
+        finally:
+            ops.FOLD_EVAL_BN = True
+        out32 = net32(x)
+    assert not any(c.startswith('cy_affine_act') for c in calls), calls
+    assert calls.count('cy_bn_fold_eval') == 4 and calls.count('cy_conv_gemm_bf16') == 4
+    assert rel_l2(out, out0) < 1e-2, rel_l2(out, out0)
+    assert rel_l2(out, out32) < 2e-2, rel_l2(out, out32)

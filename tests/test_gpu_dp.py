@@ -116,3 +116,53 @@ def test_nccl_backend_world1_bucket_and_step(tmp_path):
     port = 27500 + (os.getpid() % 2000)
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     assert (tmp_path / 'nccl_ok').exists()
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu(tmp_path):
+    """bench.py's N > 1 code path, executed: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2` exactly
+    as the driver launches it, except that the two ranks share the one GPU and the collectives go over gloo
+    (--backend gloo: RCCL wants one GPU per rank).  Covers init_from_env, broadcast_parameters, the barrier-bracketed
+    timed region, the MAX-reduce of the elapsed time, the bucket all-reduce inside the step, the all-rank pcie_inclusive
+    loop, every rank leaving the process group together BEFORE rank 0 computes its extras, and the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    from helpers import REPO
+    port = 25500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--batch', '2', '--input', '64',
+           '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--backend', 'gloo']
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['scaling'] == 'weak' and d['steps'] == 2
+    assert np.isfinite(d['value']) and d['value'] > 0
+    assert np.isfinite(d['pcie_inclusive']['value']) and d['pcie_inclusive']['value'] > 0
+    assert np.isfinite(d['config']['final_loss'])
+    assert 'cpu_baseline' not in d                                # N = 1 only
+    # rank 0's extras ran after the group was gone (they would hang or raise inside a live, half-destroyed group)
+    assert 'loss_curve_parity' in d and 'roofline_routing_c43' in d
+
+
+def test_bench_two_ranks_sync_bn_over_gloo(tmp_path):
+    """The same launch with --sync-bn: the ten small statistics all-reduces per step run inside the timed region."""
+    import json
+    import subprocess
+    import sys
+    from helpers import REPO
+    port = 23500 + (os.getpid() % 2000)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', PYTHONUNBUFFERED='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(REPO, 'bench.py'), '--gpus', '2', '--batch', '2', '--input', '64',
+           '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-extras', '--sync-bn', '--backend', 'gloo']
+    r = subprocess.run(cmd, env=env, cwd=REPO, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert d['config']['parallelism'] == 'dp2+syncbn' and np.isfinite(d['config']['final_loss'])

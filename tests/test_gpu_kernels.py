@@ -450,6 +450,50 @@ def test_conv_bn_lrelu_block(train, cin, cout, hw, B):
         assert float(seq.conv_1.bias.grad.abs().max()) == 0.0       # analytically zero in front of BN
 
 
+@pytest.mark.parametrize('cin,cout,k,stride,pad,hw,B,nchw', [
+    (128, 256, 3, 1, 1, 20, 2, False),     # fused Winograd F(2x2,3x3) forward, LeakyReLU epilogue
+    (64, 128, 3, 1, 1, 13, 3, False),      # ... odd size
+    (256, 64, 4, 2, 1, 24, 2, False),      # fused Winograd F(2x2,2x2) (4x4 / stride 2)
+    (64, 128, 4, 2, 1, 10, 3, False),
+    (128, 64, 1, 1, 0, 9, 2, False),       # implicit GEMM (DarkNet's 1x1 layers), act = 2
+    (16, 40, 3, 1, 1, 11, 2, False),       # implicit GEMM, padded channels
+    (3, 128, 3, 1, 1, 32, 2, True),        # the first layer: scale / shift in its own epilogue
+])
+def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw, B, nchw):
+    """Eval-mode conv -> BatchNorm -> LeakyReLU(0.1) as ONE launch (cy_bn_fold_eval + the conv kernel's LeakyReLU epilogue),
+    every forward kernel class, against torch fp64 modules in eval mode."""
+    from capsyolo_amd import _lib, models
+    torch.manual_seed(11)
+    conv = torch.nn.Conv2d(cin, cout, k, stride, pad).double()
+    bn = torch.nn.BatchNorm2d(cout).double()
+    bn.weight.data = (1 + 0.3 * torch.randn(cout)).double()
+    bn.bias.data = (0.2 * torch.randn(cout)).double()
+    bn.running_mean.data = (0.3 * torch.randn(cout)).double()
+    bn.running_var.data = (0.5 + torch.rand(cout)).double()
+    ref = torch.nn.Sequential(conv, bn, torch.nn.LeakyReLU(0.1)).eval()
+    seq = models.FusedBackbone()
+    seq.add_module('conv_1', models.HipConv2d(cin, cout, k, stride, pad))
+    seq.add_module('bn_1', models.HipBatchNorm2d(cout))
+    seq.add_module('relu_1', models.HipLeakyReLU(0.1))
+    seq.conv_1.load_state_dict({n: v.float() for n, v in conv.state_dict().items()})
+    seq.bn_1.load_state_dict({n: (v.float() if v.is_floating_point() else v) for n, v in bn.state_dict().items()})
+    seq.to(dev()).eval()
+    x = rnd((B, cin, hw, hw), 18)
+    with torch.no_grad():
+        yr = ref(x.double())
+        xg = (x if nchw else x.permute(0, 2, 3, 1).contiguous()).to(dev())
+        _lib.TRACE = []
+        try:
+            yh = seq(xg, nchw_in=nchw)
+            torch.cuda.synchronize()
+            calls = list(_lib.TRACE)
+        finally:
+            _lib.TRACE = None
+    assert 'cy_affine_act' not in calls, calls
+    assert ('cy_bn_fold_eval' in calls) != nchw
+    close(yh.permute(0, 3, 1, 2), yr, 1e-4, 2e-5)
+
+
 @pytest.mark.parametrize('onepass', [False, True])
 @pytest.mark.parametrize('cout,H,W,B', [(128, 32, 32, 2), (32, 33, 64, 3), (64, 6, 96, 1)])
 def test_first_block_fused_backward(cout, H, W, B, onepass):

@@ -23,7 +23,7 @@ LDS = re.compile(r'^\s+(ds_read|ds_write|ds_bpermute|ds_swizzle|ds_permute)')
 
 # (source file, extra flags, mangled-name fragments that select the kernel, minimum LDS reads of the loop to check)
 TARGETS = [
-    ('winograd.hip', [], ['wino_conv_kernelILb1', 'WinoArgsE'], 40),
+    ('winograd.hip', [], ['wino_conv_kernelILi1', 'WinoArgsE'], 40),
     ('winograd.hip', [], ['wino_wgrad_kernelILi0E'], 10),
     ('winograd.hip', [], ['wino_wgrad_kernelILi1E'], 10),
     ('winograd.hip', [], ['wino_wgrad_kernelILi2E'], 10),

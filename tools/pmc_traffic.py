@@ -24,8 +24,8 @@ def load(path, name):
 f, w = load(sys.argv[1], 'FETCH_SIZE'), load(sys.argv[2], 'WRITE_SIZE')
 # launch order inside tools/run_kernels.py: warm-up + 1 rep of each op, forward before input gradient
 pick = {
-    'conv_wino_fwd/conv_2': ('wino_conv_kernel<true>', -1),      # (with the BatchNorm statistics, as in the training step)
-    'conv_wino_dgrad/conv_2': ('wino_conv_kernel<false>', -1),
+    'conv_wino_fwd/conv_2': ('wino_conv_kernel<1>', -1),      # (with the BatchNorm statistics, as in the training step)
+    'conv_wino_dgrad/conv_2': ('wino_conv_kernel<0>', -1),
     'conv_wino_wgrad/conv_2': ('wino_wgrad_kernel<0>', 1),
     'conv_wino_wgrad_bn/conv_2': ('wino_wgrad_kernel<2>', -1),    # (premasked gradient, as in the training step)
     'routing_fwd': ('caps1_fwd_kernel<5, true>', -1),
