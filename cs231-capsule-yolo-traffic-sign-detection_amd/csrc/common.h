@@ -48,6 +48,12 @@ int cyi_rows_launch(int mode, const cyi_rows_args_t* a, const cyi_rows_plan_t* p
 long long cyi_rows_wp_floats(int N, int C, int Dout);                  // floats of the packed W image
 int cyi_rows_pack_w(const float* W, float* Wp, int N, int C, int Dout, hipStream_t s);
 
+// ---- routing_mfma.hip: the forward pass with u_hat = u W on v_mfma_f32_16x16x4_f32 (row tiles of 16; C <= 48, Dout 16 / 21)
+bool cyi_mfma_ok(int C, int Dout);
+long long cyi_mfma_wp_floats(int N, int C, int Dout);                  // floats of its packed W image
+int cyi_mfma_pack_w(const float* W, float* Wp, int N, int C, int Dout, hipStream_t s);
+int cyi_mfma_launch(const cyi_rows_args_t* a, int nch, int Dout, hipStream_t s);   // a->fused: all iterations; else one phased iteration over nch chunks of a->ic
+
 int cyi_caps_bwd_launch(const cy_routing_bwd_t* a, const float* cdb, hipStream_t s);   // routing_caps.hip: du and dW (cdb: saved couplings or NULL)
 
 #ifdef __HIPCC__

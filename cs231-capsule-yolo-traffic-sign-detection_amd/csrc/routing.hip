@@ -422,6 +422,27 @@ cyi_rows_args_t rows_args(const float* u, const float* Wp, int R, int N, int C, 
 }
 inline long long align4(long long n) { return (n + 3) & ~3ll; }
 
+// CY_ROUTING_MFMA=0: the forward of C > 1 heads on the vector kernel of routing_rows.hip instead of routing_mfma.hip (A/B runs, tests)
+inline bool mfma_enabled() {
+  const char* e = getenv("CY_ROUTING_MFMA");
+  return !(e && e[0] == '0');
+}
+inline long long fwd_wp_floats(int N, int C, int Dout) {          // the larger of the two packed W images
+  const long long a = cyi_rows_wp_floats(N, C, Dout), b = cyi_mfma_ok(C, Dout) ? cyi_mfma_wp_floats(N, C, Dout) : 0;
+  return a > b ? a : b;
+}
+// chunks of input capsules per row tile of the MFMA kernel's phased plan (few rows): about one block per CU, never more chunks
+// than the vector plan has (the workspace holds p.nch slabs)
+inline void mfma_chunks(int R, int N, const cyi_rows_plan_t& p, int* nch, int* ic) {
+  const int row_tiles = (R + 15) / 16;
+  int n = 256 / row_tiles;
+  if (n > p.nch) n = p.nch;
+  if (n > (N + 1) / 2) n = (N + 1) / 2;
+  if (n < 1) n = 1;
+  *ic = (N + n - 1) / n;
+  *nch = (N + *ic - 1) / *ic;
+}
+
 // workspace of the forward: [packed W image][phased plans: V_t, partial-sum slabs]
 template <int DOUT>
 int launch_fwd(const cy_routing_fwd_t* a, hipStream_t s) {
@@ -429,23 +450,26 @@ int launch_fwd(const cy_routing_fwd_t* a, hipStream_t s) {
   cyi_rows_plan(a->R, a->N, a->C, DOUT, 0, &p);
   if (a->ws == nullptr) return cy_set_error(CY_EINVAL, "cy_routing_fwd: this shape needs the workspace (ws) of cy_routing_fwd_ws_floats()");
   float* Wp = a->ws;
-  int rc = cyi_rows_pack_w(a->W, Wp, a->N, a->C, DOUT, s);
+  const bool mfma = mfma_enabled() && cyi_mfma_ok(a->C, DOUT);
+  int rc = mfma ? cyi_mfma_pack_w(a->W, Wp, a->N, a->C, DOUT, s) : cyi_rows_pack_w(a->W, Wp, a->N, a->C, DOUT, s);
   if (rc) return rc;
   cyi_rows_args_t r = rows_args(a->u, Wp, a->R, a->N, a->C, a->n_iter, a->gather_g, a->gather_B);
   r.s_hist = a->s_hist; r.v_out = a->v_out;
   if (!p.phased) {
     r.fused = 1; r.ic = a->N;
-    return cyi_rows_launch(0, &r, &p, DOUT, s);
+    return mfma ? cyi_mfma_launch(&r, 1, DOUT, s) : cyi_rows_launch(0, &r, &p, DOUT, s);
   }
   const long long plane = (long long)a->R * a->C * DOUT;
-  float* V = a->ws + cyi_rows_wp_floats(a->N, a->C, DOUT);
+  float* V = a->ws + fwd_wp_floats(a->N, a->C, DOUT);
   float* slab = V + align4(plane);
   const int fin_blocks = (int)cy_ceil_div((long long)a->R * a->C, 128);
+  int nch = p.nch, ic = p.ic;
+  if (mfma) mfma_chunks(a->R, a->N, p, &nch, &ic);
   for (int it = 0; it < a->n_iter; ++it) {
-    r.fused = 0; r.it = it; r.ic = p.ic; r.V = it > 0 ? V : nullptr; r.slab = slab;
-    rc = cyi_rows_launch(0, &r, &p, DOUT, s);
+    r.fused = 0; r.it = it; r.ic = ic; r.V = it > 0 ? V : nullptr; r.slab = slab;
+    rc = mfma ? cyi_mfma_launch(&r, nch, DOUT, s) : cyi_rows_launch(0, &r, &p, DOUT, s);
     if (rc) return rc;
-    slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, a->s_hist + (long long)it * plane, p.nch, plane);
+    slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, a->s_hist + (long long)it * plane, nch, plane);
     routing_fin_fwd_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(a->s_hist + (long long)it * plane, V, a->v_out, a->R, a->C, it,
                                                             it == a->n_iter - 1, a->gather_g, a->gather_B);
   }
@@ -533,7 +557,7 @@ extern "C" long long cy_routing_fwd_ws_floats(const cy_routing_fwd_t* a) {
   cyi_rows_plan_t p;
   cyi_rows_plan(a->R, a->N, a->C, a->Dout, 0, &p);
   const long long plane = (long long)a->R * a->C * a->Dout;
-  return cyi_rows_wp_floats(a->N, a->C, a->Dout) + (p.phased ? align4(plane) + p.nch * plane : 0);
+  return fwd_wp_floats(a->N, a->C, a->Dout) + (p.phased ? align4(plane) + p.nch * plane : 0);
 }
 
 extern "C" long long cy_routing_bwd_ws_floats(const cy_routing_bwd_t* a) {
