@@ -84,8 +84,8 @@ def parse():
                     help="bf16: the backbone behind the first layer on bf16 MFMA kernels (BASELINE configs[4] with --input 608 --n_iter 5)")
     ap.add_argument('--sync-bn', action='store_true', help='N>1: BatchNorm statistics over the global batch (2 small all-reduces per BN layer)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=8, help='sample batch for the CPU baseline')
-    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-batch', type=int, default=0, help='batch of the CPU baseline step (0 = --batch: the identical step)')
+    ap.add_argument('--cpu-steps', type=int, default=1)
     ap.add_argument('--no-extras', action='store_true', help='skip loss_curve_parity, roofline_routing_c43 and secondary')
     ap.add_argument('--backend', default=os.environ.get('CAPSYOLO_DP_BACKEND', 'nccl'), choices=['nccl', 'gloo'],
                     help="torch.distributed backend for N>1: 'nccl' (= RCCL over xGMI, one GPU per rank; the default) or 'gloo' "
@@ -124,26 +124,28 @@ def cpu_baseline(args, g):
     torch.manual_seed(0)
     net = OM.DarkCapsuleNet(p, n_iter=args.n_iter).train()
     opt = torch.optim.Adam([q for q in net.parameters() if q.requires_grad], lr=1e-3)
-    B = args.cpu_batch
+    B = args.cpu_batch or args.batch
     x = torch.from_numpy(synth.images(B, args.input)).permute(0, 3, 1, 2).contiguous()
     y = torch.from_numpy(synth.gtsdb_labels(B, g, 43))
 
-    def step():
-        out = net(x)
-        loss = OL.darkcapsule_loss(out, y, p)
+    def step(n):
+        out = net(x[:n])
+        loss = OL.darkcapsule_loss(out, y[:n], p)
         opt.zero_grad()
         loss.backward()
         opt.step()
         return loss.item()
-    step()                                   # warm-up
+    nw = min(B, 4)
+    step(nw)                                 # warm-up on a slice (thread pool, allocator, oneDNN primitive caches)
     t0 = time.perf_counter()
     for _ in range(args.cpu_steps):
-        step()
+        step(B)
     dt = time.perf_counter() - t0
     return {'value': round(B * args.cpu_steps / dt, 4), 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': 'oracle DarkCapsuleNet %dx%d train step, batch %d (of the %d-image batch), %d timed steps after 1 warm-up, '
-                      'torch %s CPU, %d threads' % (args.input, args.input, B, args.batch, args.cpu_steps,
-                                                    torch.__version__, cores)}
+            'sample': 'oracle DarkCapsuleNet %dx%d train step (forward + loss + backward + Adam), batch %d%s, %d timed step(s) after a '
+                      '%d-image warm-up step, torch %s CPU, %d threads'
+                      % (args.input, args.input, B, ' = the identical step' if B == args.batch else ' (of the %d-image batch)' % args.batch,
+                         args.cpu_steps, nw, torch.__version__, cores)}
 
 
 def git_head():

@@ -196,3 +196,27 @@ def test_winograd_wait_counts_cover_the_emitted_code():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_lds_waits.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "check_lds_waits: ok" in r.stdout and r.stdout.count("0 not covered") >= 5
+
+
+def test_asm_mfma_destinations_are_not_touched_before_their_last_pass():
+    """tools/check_mfma_hazards.py: in the ISA hipcc emits for the kernels whose MFMAs are inline asm (Winograd 3x3 / 4x4-stride-2,
+    bf16 GEMM, direct GEMM), no instruction reads or writes an MFMA's destination registers fewer than passes + 4 wait states behind
+    it unless it is the next MFMA of the accumulate chain -- the hazard class hipcc does not pad for asm statements (gfx950 has no
+    interlock there; symptom: run-to-run differences in lanes 48-63).  Plus the checker's own self-test on a synthetic listing."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('cy_chk_mfma', os.path.join(root, 'tools', 'check_mfma_hazards.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    early = ['\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]', '\tv_add_f32_e32 v9, v8, v8', '\tv_accvgpr_read_b32 v10, a15']
+    n, bad = chk.check_body(early, 'synthetic')
+    assert n == 1 and len(bad) == 1 and bad[0][3] == 1 and bad[0][4] == 12          # one state behind an 8-pass MFMA: needs 12
+    padded = [early[0], '\ts_nop 7', '\ts_nop 3', early[2]]
+    assert chk.check_body(padded, 'synthetic')[1] == []
+    chain = [early[0], '\tv_mfma_f32_32x32x16_bf16 a[0:15], v[0:3], v[4:7], a[0:15]'] + ['\ts_nop 7', '\ts_nop 3', early[2]]
+    assert chk.check_body(chain, 'synthetic')[1] == []                            # the accumulate chain itself needs no states
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_mfma_hazards.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert 'check_mfma_hazards: ok' in r.stdout and r.stdout.count(' 0 closer') >= 4
