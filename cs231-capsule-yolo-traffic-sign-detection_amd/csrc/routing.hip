@@ -422,10 +422,14 @@ cyi_rows_args_t rows_args(const float* u, const float* Wp, int R, int N, int C, 
 }
 inline long long align4(long long n) { return (n + 3) & ~3ll; }
 
-// CY_ROUTING_MFMA=0: the forward of C > 1 heads on the vector kernel of routing_rows.hip instead of routing_mfma.hip (A/B runs, tests)
+// CY_ROUTING_MFMA=1: the forward of C > 1 heads on routing_mfma.hip (u_hat on v_mfma_f32_16x16x4_f32) instead of the vector kernel
+// of routing_rows.hip.  OFF by default: measured slower (round 3, tools/ab_routing_mfma.py: DarkCapsuleNet3 head 5.67 ms against
+// 3.78 ms, CapsuleNet head 0.178 against 0.130 ms) -- with u_hat on the matrix cores the step is bound by what stays on the vector
+// pipe next to them (logits, softmax, weighted sums, accumulator moves: 464 vector instructions per input capsule and wave against 36
+// MFMAs) and the 16-row tiles need two rounds on 256 CUs; DESIGN section 4 has the census and what it would take.
 inline bool mfma_enabled() {
   const char* e = getenv("CY_ROUTING_MFMA");
-  return !(e && e[0] == '0');
+  return e && e[0] == '1';
 }
 inline long long fwd_wp_floats(int N, int C, int Dout) {          // the larger of the two packed W images
   const long long a = cyi_rows_wp_floats(N, C, Dout), b = cyi_mfma_ok(C, Dout) ? cyi_mfma_wp_floats(N, C, Dout) : 0;

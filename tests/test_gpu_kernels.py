@@ -450,6 +450,34 @@ def test_conv_bn_lrelu_block(train, cin, cout, hw, B):
         assert float(seq.conv_1.bias.grad.abs().max()) == 0.0       # analytically zero in front of BN
 
 
+@pytest.mark.parametrize('onepass', [False, True])
+@pytest.mark.parametrize('kind,edge', [('smooth', False), ('smooth', True)])
+def test_first_block_on_smooth_bright_images_with_zero_sum_filters(kind, edge, onepass):
+    """the patch-moment statistics (w^T M2 w - mean^2) and the one-pass backward subtract large sums; iid-noise
+    images have a near-diagonal moment matrix and hide that.  Blurred noise around +0.7 (a bright, spatially correlated image,
+    quantised to k / 128 like the data sets) with zero-sum (edge) filters makes var(z) a difference of numbers three to four
+    digits larger.  The moment matrix is accumulated EXACTLY for such images (conv1_moments.hip: products are multiples of
+    2^-14, fp32 chains flushed to double every 960 terms), so the batch variance must come out at fp32 resolution of the result
+    (measured 5.7e-8 per channel, better than the recompute path's 2e-7 .. 8e-7), and the block's gradients at 64 x 64 as close
+    to torch fp64 as the two-pass path's (measured 1.4e-6 / 1.5e-6 / 9e-8 for dW / dgamma / dbeta)."""
+    import importlib.util
+    import os
+    from helpers import REPO
+    from capsyolo_amd import ops
+    spec = importlib.util.spec_from_file_location('cy_diag_conv1', os.path.join(REPO, 'tools', 'diag_conv1_smooth.py'))
+    diag = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(diag)
+    old = ops.CONV1_MOMENTS_MIN_PIXELS
+    try:
+        r = diag.run(kind, 128, 4, 64, 64, onepass, edge)
+    finally:
+        ops.CONV1_MOMENTS_MIN_PIXELS = old
+    print(kind, edge, 'onepass' if onepass else 'twopass', r)
+    assert r['out'] <= 2e-6
+    assert r['var_elem'] <= (3e-7 if onepass else 3e-6)
+    assert r['dW'] <= 2e-5 and r['dgamma'] <= 2e-5 and r['dbeta'] <= 2e-5
+
+
 @pytest.mark.parametrize('cin,cout,k,stride,pad,hw,B,nchw', [
     (128, 256, 3, 1, 1, 20, 2, False),     # fused Winograd F(2x2,3x3) forward, LeakyReLU epilogue
     (64, 128, 3, 1, 1, 13, 3, False),      # ... odd size
@@ -609,6 +637,33 @@ def test_routing_vs_oracle(shape):
     close(v, vr, 1e-4, 1e-5)
     close(ut.grad, ur.grad, 1e-3, 1e-4)
     close(Wt.grad, Wr.grad, 1e-3, 1e-4)
+
+
+@pytest.mark.parametrize('shape', [(37, 70, 43, 8, 16, 3), (9, 33, 7, 8, 21, 2), (1100, 12, 5, 8, 16, 3), (600, 10, 7, 8, 21, 2),
+                                   (1100, 20, 43, 8, 21, 4), (1100, 16, 20, 8, 16, 5), (32, 1296, 43, 8, 16, 3), (70, 300, 43, 8, 21, 3),
+                                   (200, 64, 33, 8, 16, 3), (1000, 40, 48, 8, 21, 3)])
+def test_routing_forward_on_mfma_vs_oracle(shape, monkeypatch):
+    """The opt-in forward with u_hat = u W on v_mfma_f32_16x16x4_f32 (csrc/routing_mfma.hip, CY_ROUTING_MFMA=1: 16-row tiles,
+    capsules along the MFMA's N, output components split over the block's four waves, partial logits exchanged through LDS),
+    fused (many rows) and phased (few rows) plans, against the fp64 oracle at the tolerance of the vector kernel; the backward
+    (vector kernels) runs on the s_hist this forward leaves."""
+    from capsyolo_amd import ops
+    from oracle.models import dynamic_routing
+    monkeypatch.setenv('CY_ROUTING_MFMA', '1')
+    R, N, C, Din, Dout, n_iter = shape
+    u, W, G = rnd((R, N, Din), 11, 0.8), rnd((1, N, C, Din, Dout), 12, 0.15), rnd((R, C, Dout), 13)
+    ur, Wr = u.double().requires_grad_(True), W.double().requires_grad_(True)
+    vr = dynamic_routing(ur, Wr, n_iter)
+    (vr * G.double()).sum().backward()
+    ut, Wt = u.to(dev()).requires_grad_(True), W.to(dev()).requires_grad_(True)
+    v = ops.routing(ut, Wt, n_iter)
+    (v * G.to(dev())).sum().backward()
+    close(v, vr, 1e-4, 1e-5)
+    close(ut.grad, ur.grad, 1e-3, 1e-4)
+    close(Wt.grad, Wr.grad, 1e-3, 1e-4)
+    monkeypatch.setenv('CY_ROUTING_MFMA', '0')
+    v0 = ops.routing(u.to(dev()), W.to(dev()), n_iter)
+    close(v.detach(), v0, 2e-5, 2e-6)                 # the two forward kernels agree far inside the oracle tolerance
 
 
 @pytest.mark.parametrize('C,Dout,n_iter', [(1, 5, 3), (3, 21, 3)])
