@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         else mfma16_v(accV[p_ >= 32 ? p_ - 32 : 0][h_], fa[p_ % 3][h_][ks_], bq[br_][2 * (p_ & 1) + ks_]);   \
         if (w_ < 2 && p_ + 2 < 36) {                                                                  \
           constexpr int np_ = p_ + 2 < 36 ? p_ + 2 : 0;                                               \
-          fa[np_ % 3][w_] = *(const f32x2*)(va_ + (np_ >= 18 ? fragA_hi : fragA_lo) + np_ * 256 + w_ * 128); \
+          fa[np_ % 3][w_ & 1] = *(const f32x2*)(va_ + (np_ >= 18 ? fragA_hi : fragA_lo) + np_ * 256 + (w_ & 1) * 128); \
         }                                                                                             \
         constexpr int kind = F4S.kind[s_], k_ = F4S.idx[s_];                                          \
         if (kind == 1) {                        /* B operand of pair k_ + 6 into the ring slot pair k_ just left */ \

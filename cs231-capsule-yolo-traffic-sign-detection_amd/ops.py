@@ -134,6 +134,8 @@ USE_CONV1 = True         # 3 -> {32, 64, 128} channels, 3x3, NCHW image (the bac
 USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short reductions; kept switchable)
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
+USE_WINOGRAD4 = True     # ... forward and input gradient on F(4x4,3x3) (winograd4.hip: 1.78x fewer MFMAs) from WINOGRAD4_MIN_PIXELS output pixels on
+WINOGRAD4_MIN_PIXELS = 1 << 16
 
 
 FUSE_BN_BWD_REDUCE = True  # ... and that block's input-gradient epilogue sums the producer's BatchNorm backward
@@ -159,11 +161,13 @@ def _winograd(x, weight, bias, stats, transpose, tag, out_slope=1.0):
     Cout_l, Cin_l = weight.shape[0], weight.shape[1]
     n = Cin_l if transpose else Cout_l
     st = _stream()
-    u = _empty((query('cy_wino_packed_floats', Cg, n),), x)
-    call('cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
+    f4 = USE_WINOGRAD4 and B * H * W_ >= WINOGRAD4_MIN_PIXELS
+    u = _empty((query('cy_wino4_packed_floats' if f4 else 'cy_wino_packed_floats', Cg, n),), x)
+    call('cy_wino4_pack_weights' if f4 else 'cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
     y = _empty((B, H, W_, n), x)
     with timer.range(('conv_wino_dgrad/' if transpose else 'conv_wino_fwd/') + tag):
-        call('cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), float(out_slope), B, H, W_, Cg, n, st)
+        call('cy_conv3x3_winograd4' if f4 else 'cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats),
+             float(out_slope), B, H, W_, Cg, n, st)
     return y
 
 

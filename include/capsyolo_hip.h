@@ -154,6 +154,13 @@ long long cy_wino_packed_floats(int Cin, int N);
 int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
 int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
                         int B, int H, int W, int Cin, int Cout, void* stream);
+/* The same convolution through Winograd F(4x4,3x3) (36 multiplies per 4x4 outputs: 1.78x fewer MFMAs than F(2x2,3x3);
+ * fp32 error ~2e-6 relative; replaces the same nn.Conv2d forward / input gradient, models.py:349-351).  Same arguments
+ * and meaning as the three functions above; U has its own layout (cy_wino4_packed_floats / cy_wino4_pack_weights). */
+long long cy_wino4_packed_floats(int Cin, int N);
+int cy_wino4_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
+int cy_conv3x3_winograd4(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
+                         int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through Winograd F(3x3,2x2): dW[Cout][Cin][3][3] from X[B][H][W][Cin] and
  * dZ[B][H][W][Cout] (replaces the weight-gradient half of nn.Conv2d backward, models.py:132-223 conv_2 class of
  * layers).  Cin % 64 == 0 and Cout % 64 == 0.  ws: cy_wino_wgrad_ws_floats(B, Cin, Cout) floats (Winograd-domain

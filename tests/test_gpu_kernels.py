@@ -67,10 +67,13 @@ def test_conv_fwd_dgrad_wgrad(case):
 
 @pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10),
                                   (3, 8, 200, 64), (2, 16, 104, 128)])   # > 256 tiles: persistent blocks walk several tiles
-def test_conv3x3_winograd_matches_direct_and_fp64(case):
-    """Fused Winograd F(2x2,3x3) (forward + input gradient, bias, BN statistics, odd sizes, padded channels)
+@pytest.mark.parametrize('f4', [False, True])
+def test_conv3x3_winograd_matches_direct_and_fp64(case, f4, monkeypatch):
+    """Fused Winograd F(2x2,3x3) / F(4x4,3x3) (forward + input gradient, bias, BN statistics, odd sizes, padded channels)
     against torch fp64, and switched off against the direct implicit GEMM."""
     from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4', f4)
+    monkeypatch.setattr(ops, 'WINOGRAD4_MIN_PIXELS', 0)
     B, Cin, H, Cout = case
     x = rnd((B, Cin, H, H), 61)
     w = rnd((Cout, Cin, 3, 3), 62, (1.0 / (Cin * 9)) ** 0.5)
