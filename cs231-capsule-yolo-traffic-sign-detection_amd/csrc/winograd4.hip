@@ -25,6 +25,13 @@
 
 namespace {
 
+// developer knob for timing experiments (results are wrong when set): drop 1 the input transform's arithmetic and V stores,
+// 2 the patch loads / stores, 4 the B-operand loads, 8 the accumulator drain, 16 the transform's patch reads
+#ifndef CY_F4_DBG
+#define CY_F4_DBG 0
+#endif
+constexpr int F4DBG = CY_F4_DBG;
+
 constexpr int F4_PC = 34;                       // patch columns: 8 tiles x 4 + 2
 constexpr int F4_NPIX = 18 * F4_PC;             // 612 patch pixels
 constexpr int F4_RAWP = 625;                    // >= 612, = 1 (mod 16): the k-quad stride is 4 banks (mod 64)
@@ -34,6 +41,7 @@ constexpr int F4_NQ = 5;                        // patch float4 items per thread
 constexpr int F4_NBR = 6;                       // ring of B-operand loads per wave (position pairs in flight)
 constexpr int F4_OG = 272;                      // floats per lane group of the drain scratch: 16 pixels x 16 channels + 16 pad
 constexpr int F4_OSTEP = 4 * F4_OG;             // one drain step of a wave
+constexpr int F4_BAR = 136;                     // slot of the chunk's only barrier (the MFMAs behind it read registers only)
 
 struct Wino4Args {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
@@ -68,6 +76,27 @@ __device__ __forceinline__ f32x2 pksub(f32x2 x, f32x2 y) {
   asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
   return r;
 }
+// The B-operand ring is loaded and waited for by hand: tracked by hipcc, the loop header of the chunk loop waited vmcnt(0)
+// (the join of the loop's back edge with its entry), i.e. for the B loads issued in the chunk's last slots.  The counted
+// wait in front of a pair's first MFMA is a LOWER bound of the vector-memory operations younger than the pair's load
+// (at least 4 further ring loads; patch loads and output stores only add to them); hipcc's own vmcnt waits for the
+// patch loads stay correct, they count fewer younger operations than there are.
+template <int OFF> __device__ __forceinline__ void bload(f32x4& dst, const char* base, unsigned voff) {
+  if constexpr (CY_F4_DBG & 4) dst = f32x4{1.f, 1.f, 1.f, 1.f};
+  else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF));
+}
+__device__ __forceinline__ void bwait4(f32x4& x) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(x)); }
+// ... and so are the patch loads (a tracked load pending at the loop header draws the same vmcnt(0), which would then also
+// wait for the youngest ring loads).  A patch item is stored to LDS one chunk after its load: at least 10 vector-memory
+// operations are younger by then (first chunk of a block: 4 - q patch loads + 6 ring loads + q new patch loads; later 17+).
+__device__ __forceinline__ void rload(f32x4& dst, const char* base, unsigned voff) {
+#ifndef CY_F4_RLOAD_AUX
+#define CY_F4_RLOAD_AUX ""
+#endif
+  asm volatile("global_load_dwordx4 %0, %1, %2" CY_F4_RLOAD_AUX : "=v"(dst) : "v"(voff), "s"(base));
+}
+__device__ __forceinline__ void rwait10(f32x4& x) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(x)); }
+__device__ __forceinline__ void rwait0(f32x4& x) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); }
 __device__ __forceinline__ float acc_elem4(float a_elem) {    // one accumulator element, read where the statement stands
   float x;
   asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a_elem));
@@ -177,15 +206,19 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
   int kr = 0, cr = 0;                           // patch cursor
   unsigned smask = 0;                           // okm of the patch held in graw
   f32x4 graw[F4_NQ];
-  auto Graw1 = [&](int q, const char* xc, f32x4& dst) { dst = *(const f32x4*)(xc + goff[q]); };
+  auto Graw1 = [&](int q, const char* xc, f32x4& dst) { rload(dst, xc, goff[q]); };
   auto Sraw1 = [&](float* rb, int q, const f32x4& src, unsigned mask) {
     *(f32x4*)(rb + (q < F4_NQ - 1 ? roff0 + 512 * q : roff4)) = (mask >> q) & 1 ? src : f32x4{0.f, 0.f, 0.f, 0.f};
   };
 
   // ---- B operand stream: U[nb][chunk][wave][pair 18][lane][4]
-  const long long u_wave = 18 * 256;                                   // floats per (chunk, wave)
-  const float* ulane = a.U + (long long)wave * u_wave + lane * 4;
-  auto u_ptr = [&](int k, int c) { return ulane + ((long long)tile_pos(k).nb * nchunk + c) * (4 * u_wave); };
+  const long long u_wave = 18 * 1024;                                  // bytes per (chunk, wave)
+  unsigned ulane[5];                                                   // the lane's 16 bytes of every 1 KiB pair image, per 4 KiB window
+#pragma unroll
+  for (int k = 0; k < 5; ++k) ulane[k] = (unsigned)lane * 16u + 4096u * k;
+  auto u_ptr = [&](int k, int c) {                                     // uniform: this wave's 18 KiB of (tile k, chunk c)
+    return (const char*)a.U + (((long long)tile_pos(k).nb * nchunk + c) * 4 + wave) * u_wave;
+  };
   int ku = 0, cu = 0;
   f32x4 bq[F4_NBR];
 
@@ -262,6 +295,8 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     for (int q = 0; q < F4_NQ; ++q) Graw1(q, ximg, graw[q]);
     const unsigned m0 = okm_cur;
 #pragma unroll
+    for (int q = 0; q < F4_NQ; ++q) rwait0(graw[q]);
+#pragma unroll
     for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs, q, graw[q], m0);
     if (advance(kr, cr)) set_raw_tile(kr);
     const unsigned m1 = okm_cur;
@@ -269,6 +304,8 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     for (int q = 0; q < F4_NQ; ++q) Graw1(q, ximg + cr * 32, graw1[q]);
     __syncthreads();
     Tall(0, 0);
+#pragma unroll
+    for (int q = 0; q < F4_NQ; ++q) rwait0(graw1[q]);
 #pragma unroll
     for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs + F4_RAW_BUF, q, graw1[q], m1);
     if (advance(kr, cr)) set_raw_tile(kr);
@@ -278,11 +315,15 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     __syncthreads();
     if (advance(kr, cr)) set_raw_tile(kr);
   }
-  const float* up_cur = u_ptr(0, 0);
+  const char* up_cur = u_ptr(0, 0);
   if (advance(ku, cu)) {}
-  const float* up_nxt = u_ptr(ku, cu);
+  const char* up_nxt = u_ptr(ku, cu);
 #pragma unroll
-  for (int q = 0; q < F4_NBR; ++q) bq[q] = *(const f32x4*)(up_cur + q * 256);
+  for (int q = 0; q < F4_NBR; ++q) {
+    if (F4DBG & 4) bq[q] = f32x4{1.f, 1.f, 1.f, 1.f};
+    else if (q < 4) bload<0>(bq[q], up_cur + q * 1024, ulane[0]);
+    else bload<0>(bq[q], up_cur + (q - 4) * 1024, ulane[1]);
+  }
   const char* xp_ = ximg + cr * 32;             // G_raw(f+3)
 
   // A fragment of (position, tile half): 8 bytes at ((pos * 2 + half) * 4 + kgl) * 16 + (m ^ swizzle)
@@ -290,6 +331,11 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
   const int fragA_lo = (kgl * 16 + (ml ^ ((kgl >> 1) << 1))) * 2;           // positions 0..17
   const int fragA_hi = (kgl * 16 + (ml ^ (((kgl >> 1) << 1) | 4))) * 2;     // positions 18..35
 
+  f32x2 fa[3][2];                               // A fragments of positions p % 3; [0] / [1] are carried into the next chunk
+  fa[0][0] = *(const f32x2*)(Vs + fragA_lo);
+  fa[0][1] = *(const f32x2*)(Vs + fragA_lo + 128);
+  fa[1][0] = *(const f32x2*)(Vs + fragA_lo + 256);
+  fa[1][1] = *(const f32x2*)(Vs + fragA_lo + 256 + 128);
   int c_next = 0;
   for (int km = 0; km < ntile_mine; ++km) {
     f32x4 accA[32][2], accV[4][2];
@@ -307,30 +353,34 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
       const float* rb_ = Rs + ((c + 1) & 1) * F4_RAW_BUF;         // T(f+1) reads ...
       float* vw_ = Vs + ((c + 1) & 1) * F4_V_BUF;                 // ... and writes
       float* rw_ = Rs + (c & 1) * F4_RAW_BUF;                     // S_raw(f+2)
-      f32x2 fa[3][2];
-      fa[0][0] = *(const f32x2*)(va_ + fragA_lo);
-      fa[0][1] = *(const f32x2*)(va_ + fragA_lo + 128);
-      fa[1][0] = *(const f32x2*)(va_ + fragA_lo + 256);
-      fa[1][1] = *(const f32x2*)(va_ + fragA_lo + 256 + 128);
+#define F4_BARRIER_HERE if (s_ == F4_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #define F4SLOT(SIDX)                                                                                  \
       {                                                                                               \
         constexpr int s_ = (SIDX), p_ = s_ >> 2, w_ = s_ & 3, h_ = w_ & 1, ks_ = w_ >> 1;             \
         constexpr int q_ = p_ >> 1, br_ = q_ % F4_NBR;                                                \
+        F4_BARRIER_HERE                                                                               \
+        if (w_ == 0 && (p_ & 1) == 0 && !(F4DBG & 4)) bwait4(bq[br_]);                                \
         if (p_ < 32) mfma16_a(accA[p_ < 32 ? p_ : 0][h_], fa[p_ % 3][h_][ks_], bq[br_][2 * (p_ & 1) + ks_]); \
         else mfma16_v(accV[p_ >= 32 ? p_ - 32 : 0][h_], fa[p_ % 3][h_][ks_], bq[br_][2 * (p_ & 1) + ks_]);   \
         if (w_ < 2 && p_ + 2 < 36) {                                                                  \
           constexpr int np_ = p_ + 2 < 36 ? p_ + 2 : 0;                                               \
           fa[np_ % 3][w_ & 1] = *(const f32x2*)(va_ + (np_ >= 18 ? fragA_hi : fragA_lo) + np_ * 256 + (w_ & 1) * 128); \
+        } else if (w_ < 2) {                    /* behind the barrier: positions 0 / 1 of the NEXT chunk (fa[1] is free after slot 139) */ \
+          constexpr int np_ = p_ >= 34 ? p_ - 34 : 0;                                                             \
+          fa[np_][w_ & 1] = *(const f32x2*)(vw_ + fragA_lo + np_ * 256 + (w_ & 1) * 128);             \
         }                                                                                             \
-        constexpr int kind = F4S.kind[s_], k_ = F4S.idx[s_];                                          \
+        constexpr int kind0_ = F4S.kind[s_], k_ = F4S.idx[s_];                                        \
+        constexpr int kind = (((F4DBG & 1) && (kind0_ == 5 || kind0_ == 6)) || ((F4DBG & 2) && (kind0_ == 2 || kind0_ == 3)) || \
+                              ((F4DBG & 4) && kind0_ == 1) || ((F4DBG & 16) && kind0_ == 4)) ? 0 : kind0_;        \
         if (kind == 1) {                        /* B operand of pair k_ + 6 into the ring slot pair k_ just left */ \
           constexpr int nq_ = k_ + F4_NBR;                                                            \
-          if (nq_ < 18) bq[k_ % F4_NBR] = *(const f32x4*)(up_cur + nq_ * 256);                        \
-          else bq[k_ % F4_NBR] = *(const f32x4*)(up_nxt + (nq_ - 18) * 256);                          \
+          constexpr int lq_ = nq_ < 18 ? nq_ : nq_ - 18;                                              \
+          bload<(lq_ & 3) * 1024>(bq[k_ % F4_NBR], nq_ < 18 ? up_cur : up_nxt, ulane[lq_ >> 2]);      \
         } else if (kind == 3) {                                                                       \
-          Sraw1(rw_, k_, graw[k_], smask);                                                            \
+          rwait10(graw[k_ % F4_NQ]);                                                                       \
+          Sraw1(rw_, k_ % F4_NQ, graw[k_ % F4_NQ], smask);                                                         \
         } else if (kind == 2) {                                                                       \
-          Graw1(k_, xp_, graw[k_]);                                                                   \
+          Graw1(k_ % F4_NQ, xp_, graw[k_ % F4_NQ]);                                                                \
         } else if (kind == 4) {                                                                       \
           Trd(rb_, k_);                                                                               \
         } else if (kind == 5) {                                                                       \
@@ -349,10 +399,10 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
       F4SLOT8(72) F4SLOT8(80) F4SLOT8(88) F4SLOT8(96) F4SLOT8(104) F4SLOT8(112) F4SLOT8(120) F4SLOT8(128) F4SLOT8(136)
 #undef F4SLOT8
 #undef F4SLOT
+#undef F4_BARRIER_HERE
       up_cur = up_nxt;                          // U stream: positions f+1 / f+2
       if (advance(ku, cu)) {}
       up_nxt = u_ptr(ku, cu);
-      __syncthreads();                          // the only barrier of the chunk
     }
     // ======== tile km is complete: drain the accumulators.  V[cl&1] (cl = the tile's last position) was consumed and
     // is free until the barrier at the end of the drain: 9 KiB of it per wave are the drain's scratch.
@@ -361,7 +411,12 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     float* ow = Vs + (cl & 1) * F4_V_BUF + wave * (2 * F4_OSTEP);
     const int g_ = lane >> 4, co16 = lane & 15;
     const int co = tp.nb * 64 + wave * 16 + co16;
-    const float bv = (a.bias != nullptr && co < a.Cout) ? a.bias[co] : 0.f;
+    float bv = 0.f;                             // (one self-contained statement: a tracked load inside the tile loop made hipcc
+    if (a.bias != nullptr) {                    //  wait vmcnt(0) in the chunk loop, where its register is a temporary)
+      const float* bp = a.bias + (co < a.Cout ? co : 0);
+      asm volatile("global_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(bv) : "v"(bp));
+      if (co >= a.Cout) bv = 0.f;
+    }
     const bool full = tp.oy0 + 16 <= a.H && tp.ox0 + 32 <= a.W && tp.nb * 64 + 64 <= a.Cout && (a.Cout & 3) == 0;   // uniform
     const int pxl = lane >> 2, cq = lane & 3;                     // read-back: pixel (y, x) = (pxl >> 2, pxl & 3), channel quad
     const int cbase = tp.nb * 64 + wave * 16 + cq * 4;
@@ -431,7 +486,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         }
       }
     };
-    if (full) drain(std::true_type{}); else drain(std::false_type{});
+    if (!(F4DBG & 8)) { if (full) drain(std::true_type{}); else drain(std::false_type{}); }
     if constexpr (EPI == 1) {
       ssum += __shfl_xor(ssum, 16, 64); ssq += __shfl_xor(ssq, 16, 64);
       ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64);

@@ -135,7 +135,7 @@ USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short r
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 USE_WINOGRAD4 = True     # ... forward and input gradient on F(4x4,3x3) (winograd4.hip: 1.78x fewer MFMAs) from WINOGRAD4_MIN_PIXELS output pixels on
-WINOGRAD4_MIN_PIXELS = 1 << 16
+WINOGRAD4_MIN_PIXELS = 1 << 18   # 512 output pixels x 64 channels per block: below, its tile grid leaves most of the 256 CUs idle
 
 
 FUSE_BN_BWD_REDUCE = True  # ... and that block's input-gradient epilogue sums the producer's BatchNorm backward

@@ -481,19 +481,23 @@ def test_first_block_on_smooth_bright_images_with_zero_sum_filters(kind, edge, o
     assert r['dW'] <= 2e-5 and r['dgamma'] <= 2e-5 and r['dbeta'] <= 2e-5
 
 
-@pytest.mark.parametrize('cin,cout,k,stride,pad,hw,B,nchw', [
-    (128, 256, 3, 1, 1, 20, 2, False),     # fused Winograd F(2x2,3x3) forward, LeakyReLU epilogue
-    (64, 128, 3, 1, 1, 13, 3, False),      # ... odd size
-    (256, 64, 4, 2, 1, 24, 2, False),      # fused Winograd F(2x2,2x2) (4x4 / stride 2)
-    (64, 128, 4, 2, 1, 10, 3, False),
-    (128, 64, 1, 1, 0, 9, 2, False),       # implicit GEMM (DarkNet's 1x1 layers), act = 2
-    (16, 40, 3, 1, 1, 11, 2, False),       # implicit GEMM, padded channels
-    (3, 128, 3, 1, 1, 32, 2, True),        # the first layer: scale / shift in its own epilogue
+@pytest.mark.parametrize('cin,cout,k,stride,pad,hw,B,nchw,f4', [
+    (128, 256, 3, 1, 1, 20, 2, False, False),     # fused Winograd F(2x2,3x3) forward, LeakyReLU epilogue
+    (64, 128, 3, 1, 1, 13, 3, False, False),      # ... odd size
+    (128, 256, 3, 1, 1, 20, 2, False, True),      # fused Winograd F(4x4,3x3) forward, LeakyReLU epilogue
+    (64, 72, 3, 1, 1, 37, 3, False, True),        # ... odd size, padded channels, partial tile blocks
+    (256, 64, 4, 2, 1, 24, 2, False, False),      # fused Winograd F(2x2,2x2) (4x4 / stride 2)
+    (64, 128, 4, 2, 1, 10, 3, False, False),
+    (128, 64, 1, 1, 0, 9, 2, False, False),       # implicit GEMM (DarkNet's 1x1 layers), act = 2
+    (16, 40, 3, 1, 1, 11, 2, False, False),       # implicit GEMM, padded channels
+    (3, 128, 3, 1, 1, 32, 2, True, False),        # the first layer: scale / shift in its own epilogue
 ])
-def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw, B, nchw):
+def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw, B, nchw, f4, monkeypatch):
     """Eval-mode conv -> BatchNorm -> LeakyReLU(0.1) as ONE launch (cy_bn_fold_eval + the conv kernel's LeakyReLU epilogue),
     every forward kernel class, against torch fp64 modules in eval mode."""
-    from capsyolo_amd import _lib, models
+    from capsyolo_amd import _lib, models, ops
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4', f4)
+    monkeypatch.setattr(ops, 'WINOGRAD4_MIN_PIXELS', 0)
     torch.manual_seed(11)
     conv = torch.nn.Conv2d(cin, cout, k, stride, pad).double()
     bn = torch.nn.BatchNorm2d(cout).double()
@@ -522,6 +526,7 @@ def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw
             _lib.TRACE = None
     assert 'cy_affine_act' not in calls, calls
     assert ('cy_bn_fold_eval' in calls) != nchw
+    assert ('cy_conv3x3_winograd4' in calls) == f4
     close(yh.permute(0, 3, 1, 2), yr, 1e-4, 2e-5)
 
 

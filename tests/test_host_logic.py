@@ -220,3 +220,27 @@ def test_asm_mfma_destinations_are_not_touched_before_their_last_pass():
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_mfma_hazards.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     assert 'check_mfma_hazards: ok' in r.stdout and r.stdout.count(' 0 closer') >= 4
+
+
+def test_hand_counted_vmcnt_waits_cover_every_use_of_an_asm_loaded_register():
+    """tools/check_vmcnt.py: winograd4.hip loads its B-operand ring and its input patch with inline-asm global loads (hipcc's own
+    bookkeeping waited vmcnt(0) at the loop header) and waits with counted `s_waitcnt vmcnt(N)` statements.  The checker replays
+    the emitted instruction stream (prologue, first and steady-state chunk, across a tile's drain) with the in-order queue of
+    outstanding vector-memory operations: no instruction may touch the destination of a load that is still in the queue.  Plus a
+    self-test on a synthetic listing (a wait that is one too weak must be found)."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('cy_chk_vmcnt', os.path.join(root, 'tools', 'check_vmcnt.py'))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    loop = ['.LBB0_1:'] + ['\tv_mfma_f32_16x16x4_f32 a[0:3], v20, v21, a[0:3]'] * 144 + ['\ts_cbranch_scc1 .LBB0_1']
+    pro = ['\tglobal_load_dwordx4 v[2:5], v0, s[0:1]', '\tglobal_load_dwordx4 v[6:9], v0, s[0:1] offset:1024']
+    ok = pro + ['\ts_waitcnt vmcnt(1)', '\tv_add_f32_e32 v10, v2, v2'] + loop
+    weak = pro + ['\ts_waitcnt vmcnt(2)', '\tv_add_f32_e32 v10, v2, v2'] + loop
+    assert chk.check_kernel('synthetic', ok)[2] == []
+    assert len(chk.check_kernel('synthetic', weak)[2]) == 1
+    r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_vmcnt.py')], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert 'check_vmcnt: ok' in r.stdout and r.stdout.count(', 0 uses') == 3

@@ -1,0 +1,123 @@
+"""Static check of the hand-counted vector-memory waits of winograd4.hip (csrc): its loop loads the B-operand ring and the input
+patch with inline-asm `global_load_dwordx4` that hipcc does not count, and waits for them with `s_waitcnt vmcnt(N)` statements
+whose N is a LOWER bound of the operations younger than the load that is needed.
+
+The script compiles the file to ISA and, per kernel, replays the instruction stream in program order -- prologue, then the
+chunk loop twice (first and steady-state iteration), then once more across the drain of a tile (its stores only add younger
+operations) -- with a queue of the outstanding vector-memory operations (loads, stores, atomics: they retire in order).  Every
+`s_waitcnt vmcnt(N)` (hand-written or hipcc's) retires all but the N youngest.  An instruction that reads or writes a destination
+register of a load still in the queue is an error: the wait in front of it was too weak (or hipcc moved / copied the register
+between the load and its wait: cdna_hip_programming.md section 5.7 item 1).
+
+    python3 tools/check_vmcnt.py        # exit code 0 = every use of a loaded register stands behind a sufficient wait
+
+Run by __graft_entry__.build() and tests/test_host_logic.py (CPU only: hipcc cross-compiles)."""
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, 'cs231-capsule-yolo-traffic-sign-detection_amd', 'csrc')
+SOURCES = ['winograd4.hip']
+
+
+def regs(tok):
+    tok = tok.strip()
+    m = re.match(r'([va])\[(\d+):(\d+)\]$', tok)
+    if m:
+        return set((m.group(1), k) for k in range(int(m.group(2)), int(m.group(3)) + 1))
+    m = re.match(r'([va])(\d+)$', tok)
+    return {(m.group(1), int(m.group(2)))} if m else set()
+
+
+def parse(line):
+    m = re.match(r'^\s+([a-z_0-9]+)\s*(.*)$', line)
+    if not m:
+        return None
+    mn, rest = m.group(1), m.group(2).split(';')[0].strip()
+    ops = [o.strip().split(' ')[0] for o in re.split(r',\s*', rest) if o.strip()] if rest else []
+    return mn, ops, rest
+
+
+def kernels(asm):
+    lines = asm.split('\n')
+    out, cur, name = [], None, None
+    for l in lines:
+        m = re.match(r'^(_Z\w+):', l)
+        if m and 'kernel' in m.group(1):
+            name, cur = m.group(1), []
+        elif l.startswith('.Lfunc_end') and cur is not None:
+            out.append((name, cur)); cur = None
+        elif cur is not None:
+            cur.append(l)
+    return out
+
+
+def check_kernel(name, body):
+    idx = [i for i, l in enumerate(body) if 'v_mfma' in l]
+    if len(idx) < 144:
+        return None
+    head = idx[0]
+    while not body[head].startswith('.LBB'):
+        head -= 1
+    label = body[head].split(':')[0]
+    back = max(i for i, l in enumerate(body) if re.search(r's_c?branch\w*\s+' + re.escape(label) + r'\b', l))
+    # program order: prologue, loop, loop, drain (everything behind the loop up to the outer back edge), loop
+    order = list(range(0, head)) + list(range(head, back + 1)) * 2 + list(range(back + 1, len(body))) + list(range(head, back + 1))
+    queue, errors, nloads, nwaits = [], [], 0, 0
+    for i in order:
+        p = parse(body[i])
+        if p is None:
+            continue
+        mn, ops, rest = p
+        if mn == 's_waitcnt':
+            m = re.search(r'vmcnt\((\d+)\)', rest)
+            if m:
+                nwaits += 1
+                n = int(m.group(1))
+                while len(queue) > n:
+                    queue.pop(0)
+            continue
+        touched = set()
+        for o in ops:
+            touched |= regs(o)
+        for dst, at in queue:
+            if dst & touched:
+                errors.append('%s: line %d `%s` touches %s of the load at line %d, still in flight' %
+                              (name[:60], i, body[i].strip(), sorted(dst & touched)[:2], at))
+        if mn.startswith('global_load') or mn.startswith('buffer_load'):
+            queue.append((regs(ops[0]), i)); nloads += 1
+        elif mn.startswith('global_store') or mn.startswith('global_atomic') or mn.startswith('buffer_store'):
+            queue.append((set(), i))
+        if len(queue) > 63:
+            queue.pop(0)                      # (the counter saturates; older operations have long retired)
+    return nloads, nwaits, errors
+
+
+def main():
+    bad = 0
+    for src in SOURCES:
+        with tempfile.TemporaryDirectory() as td:
+            out = os.path.join(td, 'k.s')
+            subprocess.run(['/opt/rocm/bin/hipcc', '-O3', '-std=c++17', '--offload-arch=gfx950', '-I' + os.path.join(ROOT, 'include'),
+                            '-munsafe-fp-atomics', '-Wno-unused-result', '-S', '--cuda-device-only', '-o', out, os.path.join(CSRC, src)],
+                           check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            asm = open(out).read()
+        for name, body in kernels(asm):
+            r = check_kernel(name, body)
+            if r is None:
+                continue
+            nloads, nwaits, errors = r
+            print('%s %s: %d loads and %d vmcnt waits replayed, %d uses of a register whose load is still in flight'
+                  % (src, name[:70], nloads, nwaits, len(errors)))
+            for e in errors[:10]:
+                print('   ', e)
+            bad += len(errors)
+    print('check_vmcnt: ok' if bad == 0 else 'check_vmcnt: FAILED')
+    return 1 if bad else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())
