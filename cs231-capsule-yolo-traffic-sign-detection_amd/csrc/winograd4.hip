@@ -13,7 +13,7 @@
 // Per chunk of 8 input channels (144 MFMAs per wave):
 //   * the raw 18 x 34 input patch goes global -> registers -> LDS ([k-quad][pixel][4]),
 //   * every thread transforms HALF an item (tile, channel pair): rows 0..2 or 3..5 of V = B^T d B (72 v_pk_fma_f32) and
-//     writes them into the A-operand image V[pos][tile half][k pair][tile (swizzled)][2 k-steps],
+//     writes them into the A-operand image V[pos][k pair][tile slot (swizzled)][tile half][2 k-steps],
 //   * the transformed weights never touch LDS: they are packed per call in the B-operand order of each wave
 //     (U[co block][chunk][wave][position pair][lane][4]) and stream global/L2 -> registers through a ring of 6
 //     dwordx4 loads per wave, each issued 48 MFMAs before its first use.
@@ -36,7 +36,7 @@ constexpr int F4_PC = 34;                       // patch columns: 8 tiles x 4 + 
 constexpr int F4_NPIX = 18 * F4_PC;             // 612 patch pixels
 constexpr int F4_RAWP = 625;                    // >= 612, = 1 (mod 16): the k-quad stride is 4 banks (mod 64)
 constexpr int F4_RAW_BUF = 2 * F4_RAWP * 4;     // floats: [kq][pixel][4]
-constexpr int F4_V_BUF = 36 * 256;              // floats: [pos][tile half][kg][16 tile slots][2]
+constexpr int F4_V_BUF = 36 * 256;              // floats: [pos][kg][16 tile slots][tile half][2 k-steps]
 constexpr int F4_NQ = 5;                        // patch float4 items per thread (1224 over 256 threads)
 constexpr int F4_NBR = 6;                       // ring of B-operand loads per wave (position pairs in flight)
 constexpr int F4_OG = 272;                      // floats per lane group of the drain scratch: 16 pixels x 16 channels + 16 pad
@@ -89,11 +89,15 @@ __device__ __forceinline__ void bwait4(f32x4& x) { asm volatile("s_waitcnt vmcnt
 // ... and so are the patch loads (a tracked load pending at the loop header draws the same vmcnt(0), which would then also
 // wait for the youngest ring loads).  A patch item is stored to LDS one chunk after its load: at least 10 vector-memory
 // operations are younger by then (first chunk of a block: 4 - q patch loads + 6 ring loads + q new patch loads; later 17+).
-__device__ __forceinline__ void rload(f32x4& dst, const char* base, unsigned voff) {
+// The patch is read through a buffer descriptor of ONE image (base = the image, num_records = its bytes): a padding item
+// gets an offset beyond the image and the hardware's range check returns zeros -- no select, no zero page, no masks; the
+// chunk's channel offset travels as the instruction's scalar offset (no vector add per chunk).
+typedef int i32x4_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void rload(f32x4& dst, i32x4_ desc, unsigned voff, unsigned soff) {
 #ifndef CY_F4_RLOAD_AUX
 #define CY_F4_RLOAD_AUX ""
 #endif
-  asm volatile("global_load_dwordx4 %0, %1, %2" CY_F4_RLOAD_AUX : "=v"(dst) : "v"(voff), "s"(base));
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" CY_F4_RLOAD_AUX : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff));
 }
 __device__ __forceinline__ void rwait10(f32x4& x) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(x)); }
 __device__ __forceinline__ void rwait0(f32x4& x) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); }
@@ -104,8 +108,8 @@ __device__ __forceinline__ float acc_elem4(float a_elem) {    // one accumulator
 }
 
 // ---- compile-time schedule of one chunk: 144 slots; slot s issues the MFMA of position s >> 2, tile half s & 1, k-step
-// (s >> 1) & 1 (consecutive MFMAs alternate between the position's two accumulators).  The two A fragments of position
-// p + 2 are fetched in slots 4p and 4p + 1.  Side work, one piece per slot, only in slots 4p + 2 and 4p + 3:
+// (s >> 1) & 1 (consecutive MFMAs alternate between the position's two accumulators).  The A fragment of position p + 2 (both
+// tile halves, both k-steps: one ds_read_b128) is fetched in slot 4p.  Side work, one piece per slot, only in slots 4p + 2 and 4p + 3:
 //   1 G_B    B operand of position pair q + 6 (ring slot q % 6), right behind the last MFMA of pair q
 //   3 S_raw  one float4 of the patch of chunk f + 2: registers -> LDS        2 G_raw  one patch load of chunk f + 3
 //   4 T_rd   one column (7 float2) of the thread's patch of chunk f + 1      5 T_col  half a column of T = B^T d
@@ -179,23 +183,20 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
   const int roff0 = (kq_of_thread * F4_RAWP + pix0) * 4;
   const bool rlast_ok = pix0 + 128 * (F4_NQ - 1) < F4_NPIX;
   const int roff4 = roff0 + 512 * (rlast_ok ? F4_NQ - 1 : F4_NQ - 2);
-  unsigned gvoff[F4_NQ];                        // byte offset of the item's pixel, channel quad, from the image base
-  unsigned okm_cur = 0;                         // bit q: item q of the patch cursor's tile is an image pixel
-  unsigned goff[F4_NQ];                         // gvoff, or 0 for padding items (a valid address; stored as exact zeros)
-  const char* ximg = nullptr;                   // uniform
+  unsigned goff[F4_NQ];                         // byte offset of the item's pixel, channel quad, from the image base; padding: 2^31
+  i32x4_ xdesc = {0, 0, 0, 0};                  // uniform: buffer descriptor of the patch cursor's image
+  const int img_bytes = a.H * a.W * a.Cin * 4;
   auto set_raw_tile = [&](int k) {
     const TilePos p = tile_pos(k);
-    ximg = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin);
-    okm_cur = 0;
+    const unsigned long long xb = (unsigned long long)(uintptr_t)(a.X + (long long)p.b * a.H * a.W * a.Cin);
+    xdesc = i32x4_{(int)(unsigned)xb, (int)(unsigned)((xb >> 32) & 0xffffu), img_bytes, 0x00020000};
 #pragma unroll
     for (int q = 0; q < F4_NQ; ++q) {
       const int pix = pix0 + 128 * ((q < F4_NQ - 1 || rlast_ok) ? q : q - 1);
       const int pr = pix / F4_PC, pc = pix - pr * F4_PC;
       const int iy = p.oy0 - 1 + pr, ix = p.ox0 - 1 + pc;
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      gvoff[q] = (unsigned)(((iy * a.W + ix) * a.Cin + kq_of_thread * 4) * 4);
-      okm_cur |= (unsigned)ok << q;
-      goff[q] = ok ? gvoff[q] : 0u;
+      goff[q] = ok ? (unsigned)(((iy * a.W + ix) * a.Cin + kq_of_thread * 4) * 4) : 0x80000000u;
     }
   };
   auto advance = [&](int& k, int& c) {          // one chunk further; stops at the very last chunk of the block's stream
@@ -204,12 +205,9 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     return false;
   };
   int kr = 0, cr = 0;                           // patch cursor
-  unsigned smask = 0;                           // okm of the patch held in graw
   f32x4 graw[F4_NQ];
-  auto Graw1 = [&](int q, const char* xc, f32x4& dst) { rload(dst, xc, goff[q]); };
-  auto Sraw1 = [&](float* rb, int q, const f32x4& src, unsigned mask) {
-    *(f32x4*)(rb + (q < F4_NQ - 1 ? roff0 + 512 * q : roff4)) = (mask >> q) & 1 ? src : f32x4{0.f, 0.f, 0.f, 0.f};
-  };
+  auto Graw1 = [&](int q, int c, f32x4& dst) { rload(dst, xdesc, goff[q], (unsigned)c * 32u); };
+  auto Sraw1 = [&](float* rb, int q, const f32x4& src) { *(f32x4*)(rb + (q < F4_NQ - 1 ? roff0 + 512 * q : roff4)) = src; };
 
   // ---- B operand stream: U[nb][chunk][wave][pair 18][lane][4]
   const long long u_wave = 18 * 1024;                                  // bytes per (chunk, wave)
@@ -226,8 +224,8 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
   const int hr = t & 1, kg = (t >> 1) & 3, ttx = (t >> 3) & 7, tty = t >> 6;
   const int tbase = ((kg >> 1) * F4_RAWP + (4 * tty) * F4_PC + 4 * ttx) * 4 + 2 * (kg & 1);   // patch pixel (0, 0)
   const int tbase_e = tbase + hr * F4_PC * 4;                                                   // rows hr, 2 + hr, 4 + hr
-  const int tslot = ((tty & 1) * 8 + ttx) ^ (((kg >> 1) << 1) | (hr << 2));
-  const int vdst = (((tty >> 1) * 4 + kg) * 16 + tslot) * 2;
+  const int tslot = ((tty & 1) * 8 + ttx) ^ ((kg << 1) | (hr << 3));
+  const int vdst = (kg * 16 + tslot) * 4 + (tty >> 1) * 2;
   // outputs of the column pass: o0 = 4 e0 - 5 e1 + e2 (row 0 / 5), o1 / o2 = X +- gamma Y (rows 1, 2 / 3, 4)
   const int vd0 = vdst + (hr ? 30 : 0) * 256, vd1 = vdst + (hr ? 18 : 6) * 256, vd2 = vdst + (hr ? 24 : 12) * 256;
   const float alpha_ = hr ? -1.f : -4.f, gamma_ = hr ? 2.f : 1.f;
@@ -292,26 +290,23 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     f32x4 graw1[F4_NQ];
     set_raw_tile(0);
 #pragma unroll
-    for (int q = 0; q < F4_NQ; ++q) Graw1(q, ximg, graw[q]);
-    const unsigned m0 = okm_cur;
+    for (int q = 0; q < F4_NQ; ++q) Graw1(q, 0, graw[q]);
 #pragma unroll
     for (int q = 0; q < F4_NQ; ++q) rwait0(graw[q]);
 #pragma unroll
-    for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs, q, graw[q], m0);
+    for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs, q, graw[q]);
     if (advance(kr, cr)) set_raw_tile(kr);
-    const unsigned m1 = okm_cur;
 #pragma unroll
-    for (int q = 0; q < F4_NQ; ++q) Graw1(q, ximg + cr * 32, graw1[q]);
+    for (int q = 0; q < F4_NQ; ++q) Graw1(q, cr, graw1[q]);
     __syncthreads();
     Tall(0, 0);
 #pragma unroll
     for (int q = 0; q < F4_NQ; ++q) rwait0(graw1[q]);
 #pragma unroll
-    for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs + F4_RAW_BUF, q, graw1[q], m1);
+    for (int q = 0; q < F4_NQ; ++q) Sraw1(Rs + F4_RAW_BUF, q, graw1[q]);
     if (advance(kr, cr)) set_raw_tile(kr);
-    smask = okm_cur;
 #pragma unroll
-    for (int q = 0; q < F4_NQ; ++q) Graw1(q, ximg + cr * 32, graw[q]);
+    for (int q = 0; q < F4_NQ; ++q) Graw1(q, cr, graw[q]);
     __syncthreads();
     if (advance(kr, cr)) set_raw_tile(kr);
   }
@@ -324,18 +319,15 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     else if (q < 4) bload<0>(bq[q], up_cur + q * 1024, ulane[0]);
     else bload<0>(bq[q], up_cur + (q - 4) * 1024, ulane[1]);
   }
-  const char* xp_ = ximg + cr * 32;             // G_raw(f+3)
 
   // A fragment of (position, tile half): 8 bytes at ((pos * 2 + half) * 4 + kgl) * 16 + (m ^ swizzle)
   const int kgl = lane >> 4, ml = lane & 15;
-  const int fragA_lo = (kgl * 16 + (ml ^ ((kgl >> 1) << 1))) * 2;           // positions 0..17
-  const int fragA_hi = (kgl * 16 + (ml ^ (((kgl >> 1) << 1) | 4))) * 2;     // positions 18..35
+  const int fragA_lo = (kgl * 16 + (ml ^ (kgl << 1))) * 4;                  // positions 0..17
+  const int fragA_hi = (kgl * 16 + (ml ^ ((kgl << 1) | 8))) * 4;            // positions 18..35
 
-  f32x2 fa[3][2];                               // A fragments of positions p % 3; [0] / [1] are carried into the next chunk
-  fa[0][0] = *(const f32x2*)(Vs + fragA_lo);
-  fa[0][1] = *(const f32x2*)(Vs + fragA_lo + 128);
-  fa[1][0] = *(const f32x2*)(Vs + fragA_lo + 256);
-  fa[1][1] = *(const f32x2*)(Vs + fragA_lo + 256 + 128);
+  f32x4 fa[3];                                  // A fragments (both tile halves x 2 k-steps) of positions p % 3; [0] / [1] are carried into the next chunk
+  fa[0] = *(const f32x4*)(Vs + fragA_lo);
+  fa[1] = *(const f32x4*)(Vs + fragA_lo + 256);
   int c_next = 0;
   for (int km = 0; km < ntile_mine; ++km) {
     f32x4 accA[32][2], accV[4][2];
@@ -360,14 +352,14 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         constexpr int q_ = p_ >> 1, br_ = q_ % F4_NBR;                                                \
         F4_BARRIER_HERE                                                                               \
         if (w_ == 0 && (p_ & 1) == 0 && !(F4DBG & 4)) bwait4(bq[br_]);                                \
-        if (p_ < 32) mfma16_a(accA[p_ < 32 ? p_ : 0][h_], fa[p_ % 3][h_][ks_], bq[br_][2 * (p_ & 1) + ks_]); \
-        else mfma16_v(accV[p_ >= 32 ? p_ - 32 : 0][h_], fa[p_ % 3][h_][ks_], bq[br_][2 * (p_ & 1) + ks_]);   \
-        if (w_ < 2 && p_ + 2 < 36) {                                                                  \
+        if (p_ < 32) mfma16_a(accA[p_ < 32 ? p_ : 0][h_], fa[p_ % 3][2 * h_ + ks_], bq[br_][2 * (p_ & 1) + ks_]); \
+        else mfma16_v(accV[p_ >= 32 ? p_ - 32 : 0][h_], fa[p_ % 3][2 * h_ + ks_], bq[br_][2 * (p_ & 1) + ks_]);   \
+        if (w_ == 0 && p_ + 2 < 36) {                                                                 \
           constexpr int np_ = p_ + 2 < 36 ? p_ + 2 : 0;                                               \
-          fa[np_ % 3][w_ & 1] = *(const f32x2*)(va_ + (np_ >= 18 ? fragA_hi : fragA_lo) + np_ * 256 + (w_ & 1) * 128); \
-        } else if (w_ < 2) {                    /* behind the barrier: positions 0 / 1 of the NEXT chunk (fa[1] is free after slot 139) */ \
+          fa[np_ % 3] = *(const f32x4*)(va_ + (np_ >= 18 ? fragA_hi : fragA_lo) + np_ * 256);         \
+        } else if (w_ == 0) {                   /* behind the barrier: positions 0 / 1 of the NEXT chunk (fa[1] is free after slot 139) */ \
           constexpr int np_ = p_ >= 34 ? p_ - 34 : 0;                                                             \
-          fa[np_][w_ & 1] = *(const f32x2*)(vw_ + fragA_lo + np_ * 256 + (w_ & 1) * 128);             \
+          fa[np_] = *(const f32x4*)(vw_ + fragA_lo + np_ * 256);                                      \
         }                                                                                             \
         constexpr int kind0_ = F4S.kind[s_], k_ = F4S.idx[s_];                                        \
         constexpr int kind = (((F4DBG & 1) && (kind0_ == 5 || kind0_ == 6)) || ((F4DBG & 2) && (kind0_ == 2 || kind0_ == 3)) || \
@@ -378,9 +370,9 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
           bload<(lq_ & 3) * 1024>(bq[k_ % F4_NBR], nq_ < 18 ? up_cur : up_nxt, ulane[lq_ >> 2]);      \
         } else if (kind == 3) {                                                                       \
           rwait10(graw[k_ % F4_NQ]);                                                                       \
-          Sraw1(rw_, k_ % F4_NQ, graw[k_ % F4_NQ], smask);                                                         \
+          Sraw1(rw_, k_ % F4_NQ, graw[k_ % F4_NQ]);                                                         \
         } else if (kind == 2) {                                                                       \
-          Graw1(k_ % F4_NQ, xp_, graw[k_ % F4_NQ]);                                                                \
+          Graw1(k_ % F4_NQ, cr, graw[k_ % F4_NQ]);                                                                \
         } else if (kind == 4) {                                                                       \
           Trd(rb_, k_);                                                                               \
         } else if (kind == 5) {                                                                       \
@@ -388,9 +380,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         } else if (kind == 6) {                                                                       \
           Trow(vw_, k_ >> 2, k_ & 3);                                                                 \
         } else if (kind == 7) {                 /* graw now holds f+3; patch cursor -> f+4 */         \
-          smask = okm_cur;                                                                            \
           if (advance(kr, cr)) set_raw_tile(kr);                                                      \
-          xp_ = ximg + cr * 32;                                                                       \
         }                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                            \
       }
@@ -486,7 +476,62 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         }
       }
     };
-    if (!(F4DBG & 8)) { if (full) drain(std::true_type{}); else drain(std::false_type{}); }
+    // Blocks inside the image (all of them at 416 x 416 and 608 x 608): two tiles (accumulator registers r, r + 1) per step as
+    // float2 -- one wave per SIMD issues one vector instruction per 4 cycles, packed or not, so v_pk_* halves the drain's
+    // arithmetic time (transform, bias, statistics); no range checks.
+    auto drain_full = [&]() {
+      const f32x2 k2 = {2.f, 2.f}, k4 = {4.f, 4.f}, k8 = {8.f, 8.f}, bv2 = {bv, bv};
+      f32x2 ssum2 = {0.f, 0.f}, ssq2 = {0.f, 0.f};
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int h = sp >> 1, r0 = 2 * (sp & 1);
+        f32x2 S[6][4];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          f32x2 m[6];
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            const int p = 6 * i + j;
+            m[j][0] = p < 32 ? acc_elem4(accA[p < 32 ? p : 0][h][r0]) : accV[p >= 32 ? p - 32 : 0][h][r0];
+            m[j][1] = p < 32 ? acc_elem4(accA[p < 32 ? p : 0][h][r0 + 1]) : accV[p >= 32 ? p - 32 : 0][h][r0 + 1];
+          }
+          const f32x2 s12 = pkadd(m[1], m[2]), d12 = pksub(m[1], m[2]), s34 = pkadd(m[3], m[4]), d34 = pksub(m[3], m[4]);
+          S[i][0] = pkadd(pkadd(m[0], s12), s34);
+          S[i][1] = pkfma(k2, d34, d12);
+          S[i][2] = pkfma(k4, s34, s12);
+          S[i][3] = pkadd(pkfma(k8, d34, d12), m[5]);
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const f32x2 s12 = pkadd(pkadd(S[1][x], S[2][x]), bv2), d12 = pkadd(pksub(S[1][x], S[2][x]), bv2);   // (the bias rides on them)
+          const f32x2 s34 = pkadd(S[3][x], S[4][x]), d34 = pksub(S[3][x], S[4][x]);
+          f32x2 y[4];
+          y[0] = pkadd(pkadd(S[0][x], s12), s34);
+          y[1] = pkfma(k2, d34, d12);
+          y[2] = pkfma(k4, s34, s12);
+          y[3] = pkadd(pkfma(k8, d34, d12), S[5][x]);
+#pragma unroll
+          for (int yy = 0; yy < 4; ++yy) {
+            f32x2 v = y[yy];
+            if constexpr (EPI == 2) { v[0] = fmaxf(v[0], v[0] * a.out_slope); v[1] = fmaxf(v[1], v[1] * a.out_slope); }
+            ow[g_ * F4_OG + (yy * 4 + x) * 16 + co16] = v[0];
+            ow[F4_OSTEP + g_ * F4_OG + (yy * 4 + x) * 16 + co16] = v[1];
+            if constexpr (EPI == 1) { ssum2 = pkadd(ssum2, v); ssq2 = pkfma(v, v, ssq2); }
+          }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int Tj = 16 * h + 4 * j + r0 + rr;
+            const f32x4 v = *(const f32x4*)(ow + rr * F4_OSTEP + j * F4_OG + pxl * 16 + cq * 4);
+            float* yp = ybase + ((long long)(4 * (Tj >> 3)) * a.W + 4 * (Tj & 7)) * a.Cout + lane_off;
+            *(f32x4*)yp = v;
+          }
+      }
+      ssum = ssum2[0] + ssum2[1]; ssq = ssq2[0] + ssq2[1];
+    };
+    if (!(F4DBG & 8)) { if (full) drain_full(); else drain(std::false_type{}); }
     if constexpr (EPI == 1) {
       ssum += __shfl_xor(ssum, 16, 64); ssq += __shfl_xor(ssq, 16, 64);
       ssum += __shfl_xor(ssum, 32, 64); ssq += __shfl_xor(ssq, 32, 64);

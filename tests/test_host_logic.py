@@ -235,7 +235,7 @@ def test_hand_counted_vmcnt_waits_cover_every_use_of_an_asm_loaded_register():
     spec = importlib.util.spec_from_file_location('cy_chk_vmcnt', os.path.join(root, 'tools', 'check_vmcnt.py'))
     chk = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(chk)
-    loop = ['.LBB0_1:'] + ['\tv_mfma_f32_16x16x4_f32 a[0:3], v20, v21, a[0:3]'] * 144 + ['\ts_cbranch_scc1 .LBB0_1']
+    loop = ['.LBB0_1:'] + ['\tv_mfma_f32_16x16x4_f32 a[0:3], v20, v21, a[0:3]'] * 144 + ['\ts_cbranch_scc1 .LBB0_1', '\ts_endpgm']
     pro = ['\tglobal_load_dwordx4 v[2:5], v0, s[0:1]', '\tglobal_load_dwordx4 v[6:9], v0, s[0:1] offset:1024']
     ok = pro + ['\ts_waitcnt vmcnt(1)', '\tv_add_f32_e32 v10, v2, v2'] + loop
     weak = pro + ['\ts_waitcnt vmcnt(2)', '\tv_add_f32_e32 v10, v2, v2'] + loop

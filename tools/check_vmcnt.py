@@ -2,9 +2,9 @@
 patch with inline-asm `global_load_dwordx4` that hipcc does not count, and waits for them with `s_waitcnt vmcnt(N)` statements
 whose N is a LOWER bound of the operations younger than the load that is needed.
 
-The script compiles the file to ISA and, per kernel, replays the instruction stream in program order -- prologue, then the
-chunk loop twice (first and steady-state iteration), then once more across the drain of a tile (its stores only add younger
-operations) -- with a queue of the outstanding vector-memory operations (loads, stores, atomics: they retire in order).  Every
+The script compiles the file to ISA and, per kernel, walks EVERY control-flow path of the emitted code (both sides of each
+conditional branch; a loop is re-entered until the state at its labels repeats) with the queue of the outstanding vector-memory
+operations (loads, stores, atomics: they retire in order) as the state.  Every
 `s_waitcnt vmcnt(N)` (hand-written or hipcc's) retires all but the N youngest.  An instruction that reads or writes a destination
 register of a load still in the queue is an error: the wait in front of it was too weak (or hipcc moved / copied the register
 between the load and its wait: cdna_hip_programming.md section 5.7 item 1).
@@ -55,45 +55,66 @@ def kernels(asm):
     return out
 
 
-def check_kernel(name, body):
-    idx = [i for i, l in enumerate(body) if 'v_mfma' in l]
-    if len(idx) < 144:
+def check_kernel(name, body, max_steps=20000000):
+    """Walks every control-flow path of the kernel (both sides of each conditional branch, loops until the state repeats) with the
+    in-order queue of outstanding vector-memory operations as the state."""
+    if sum(1 for l in body if 'v_mfma' in l) < 144:
         return None
-    head = idx[0]
-    while not body[head].startswith('.LBB'):
-        head -= 1
-    label = body[head].split(':')[0]
-    back = max(i for i, l in enumerate(body) if re.search(r's_c?branch\w*\s+' + re.escape(label) + r'\b', l))
-    # program order: prologue, loop, loop, drain (everything behind the loop up to the outer back edge), loop
-    order = list(range(0, head)) + list(range(head, back + 1)) * 2 + list(range(back + 1, len(body))) + list(range(head, back + 1))
-    queue, errors, nloads, nwaits = [], [], 0, 0
-    for i in order:
-        p = parse(body[i])
-        if p is None:
-            continue
-        mn, ops, rest = p
-        if mn == 's_waitcnt':
-            m = re.search(r'vmcnt\((\d+)\)', rest)
-            if m:
-                nwaits += 1
-                n = int(m.group(1))
-                while len(queue) > n:
-                    queue.pop(0)
-            continue
-        touched = set()
-        for o in ops:
-            touched |= regs(o)
-        for dst, at in queue:
-            if dst & touched:
-                errors.append('%s: line %d `%s` touches %s of the load at line %d, still in flight' %
-                              (name[:60], i, body[i].strip(), sorted(dst & touched)[:2], at))
-        if mn.startswith('global_load') or mn.startswith('buffer_load'):
-            queue.append((regs(ops[0]), i)); nloads += 1
-        elif mn.startswith('global_store') or mn.startswith('global_atomic') or mn.startswith('buffer_store'):
-            queue.append((set(), i))
-        if len(queue) > 63:
-            queue.pop(0)                      # (the counter saturates; older operations have long retired)
-    return nloads, nwaits, errors
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r'^(\.L\w+):', l)
+        if m:
+            labels[m.group(1)] = i
+    instrs = [parse(l) for l in body]
+    errors, seen, nloads, nwaits = {}, set(), set(), set()
+    stack = [(0, ())]
+    steps = 0
+    while stack:
+        pc, queue = stack.pop()
+        queue = list(queue)
+        while pc < len(body):
+            key = None
+            if body[pc].startswith('.L'):
+                key = (pc, tuple(queue))
+                if key in seen:
+                    break
+                seen.add(key)
+            p = instrs[pc]
+            pc += 1
+            if p is None:
+                continue
+            steps += 1
+            if steps > max_steps:
+                raise RuntimeError('check_vmcnt: path walk does not converge')
+            mn, ops, rest = p
+            if mn == 's_waitcnt':
+                m = re.search(r'vmcnt\((\d+)\)', rest)
+                if m:
+                    nwaits.add(pc)
+                    n = int(m.group(1))
+                    while len(queue) > n:
+                        queue.pop(0)
+                continue
+            if mn == 's_endpgm':
+                break
+            touched = set()
+            for o in ops:
+                touched |= regs(o)
+            for dst, at in queue:
+                if dst & touched:
+                    errors[(pc - 1, at)] = '%s: line %d `%s` touches %s of the load at line %d, still in flight' % (
+                        name[:60], pc - 1, body[pc - 1].strip(), sorted(dst & touched)[:2], at)
+            if mn.startswith('global_load') or mn.startswith('buffer_load'):
+                queue.append((frozenset(regs(ops[0])), pc - 1)); nloads.add(pc)
+            elif mn.startswith('global_store') or mn.startswith('global_atomic') or mn.startswith('buffer_store'):
+                queue.append((frozenset(), -1))
+            if len(queue) > 63:
+                queue.pop(0)                  # (the counter saturates; older operations have long retired)
+            if mn == 's_branch':
+                pc = labels[ops[0]]
+            elif mn.startswith('s_cbranch'):
+                stack.append((labels[ops[0]], tuple(queue)))
+    return len(nloads), len(nwaits), list(errors.values())
 
 
 def main():
@@ -110,7 +131,7 @@ def main():
             if r is None:
                 continue
             nloads, nwaits, errors = r
-            print('%s %s: %d loads and %d vmcnt waits replayed, %d uses of a register whose load is still in flight'
+            print('%s %s: %d loads and %d vmcnt waits on the walked paths, %d uses of a register whose load is still in flight'
                   % (src, name[:70], nloads, nwaits, len(errors)))
             for e in errors[:10]:
                 print('   ', e)
