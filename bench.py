@@ -11,7 +11,7 @@ One step = forward + darkcapsule_loss + backward + (N>1: one RCCL all-reduce of 
 same step fed from host memory through the device-side input pipeline is `pcie_inclusive`.  Rank 0 prints ONE JSON
 line.  Extra objects on that line:
   roofline      dominant kernel (conv_2's fused Winograd kernel, fp32 MFMA): the MFMA FLOPs the kernel ISSUES per launch
-                (direct-convolution FLOPs / 2.25) divided by the launch's mean duration (HIP events on the launch stream
+                (direct-convolution FLOPs / 2.25; / 4 for the F(4x4,3x3) forward / input gradient) divided by the launch's mean duration (HIP events on the launch stream
                 inside the timed steps) and by the fp32 MFMA peak; `effective_vs_direct` prices the same time against the
                 direct-convolution FLOPs (can exceed 1); `traffic` = HBM bytes from the newest PMC passes in profiles/
   roofline_routing       the C = 1 routing kernel of this model (HBM-bound): algorithmic bytes / duration
@@ -326,6 +326,7 @@ def _dominant(ops, flops, steps, peak_by_prefix):
 
 _KIND_PEAKS = {   # timer key prefix -> (issued / direct-convolution FLOPs, MFMA peak of the arithmetic type)
     'conv_wino_fwd': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino_dgrad': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS),
+    'conv_wino4_fwd': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino4_dgrad': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino_wgrad': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino_wgrad_bn': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_fwd': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino2_dgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_wgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_gemm_fwd': (1.0, PEAK_FP32_MATRIX_TFLOPS),
@@ -511,6 +512,8 @@ def main():
         cands = []
         for key, kname, executed, peak in ((k_, n_, e_, PEAK_FP32_MATRIX_TFLOPS) for k_, n_, e_ in (
                 ('conv_wino_fwd/conv_2', 'wino_conv_kernel (conv_2 forward, fused Winograd F(2x2,3x3), fp32 MFMA)', 1 / 2.25),
+                ('conv_wino4_fwd/conv_2', 'wino4_conv_kernel<1> (conv_2 forward, fused Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, with the BatchNorm statistics)', 1 / 4.0),
+                ('conv_wino4_dgrad/conv_2', 'wino4_conv_kernel<0> (conv_2 input gradient, fused Winograd F(4x4,3x3))', 1 / 4.0),
                 ('conv_gemm_fwd/conv_2', 'conv_gemm_kernel<2,true> (conv_2 forward, implicit GEMM, fp32 MFMA)', 1.0),
                 ('conv_wino_dgrad/conv_2', 'wino_conv_kernel (conv_2 input gradient, fused Winograd F(2x2,3x3))', 1 / 2.25),
                 ('conv_gemm_dgrad/conv_2', 'conv_gemm_kernel<2,true> (conv_2 input gradient, implicit GEMM)', 1.0),
@@ -539,7 +542,7 @@ def main():
                                                  if tr else None),
                               'launch_ms': round(ms, 4), 'launches_timed': n,
                               'note': 'achieved = issued MFMA FLOPs (direct-convolution 2*M*N*K = %.3f TFLOP with M=%d, N=256, '
-                                      'K=1152, / 2.25 for the F(2x2,3x3) Winograd kernels) / mean launch time; '
+                                      'K=1152, / 2.25 for the F(2x2,3x3) / F(3x3,2x2) Winograd kernels, / 4 for F(4x4,3x3)) / mean launch time; '
                                       'effective_vs_direct = direct-convolution FLOPs / time / peak' % (conv2_flops / 1e12, M)})
         cands.sort(key=lambda d: -d['launch_ms'])
         R = g * g * B

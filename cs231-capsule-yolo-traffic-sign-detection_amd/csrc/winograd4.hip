@@ -38,10 +38,18 @@ constexpr int F4_RAWP = 625;                    // >= 612, = 1 (mod 16): the k-q
 constexpr int F4_RAW_BUF = 2 * F4_RAWP * 4;     // floats: [kq][pixel][4]
 constexpr int F4_V_BUF = 36 * 256;              // floats: [pos][kg][16 tile slots][tile half][2 k-steps]
 constexpr int F4_NQ = 5;                        // patch float4 items per thread (1224 over 256 threads)
-constexpr int F4_NBR = 6;                       // ring of B-operand loads per wave (position pairs in flight)
+#ifndef CY_F4_NBR
+#define CY_F4_NBR 9
+#endif
+constexpr int F4_NBR = CY_F4_NBR;              // ring of B-operand loads per wave (position pairs in flight; divides 18)
 constexpr int F4_OG = 272;                      // floats per lane group of the drain scratch: 16 pixels x 16 channels + 16 pad
 constexpr int F4_OSTEP = 4 * F4_OG;             // one drain step of a wave
 constexpr int F4_BAR = 136;                     // slot of the chunk's only barrier (the MFMAs behind it read registers only)
+
+#ifdef CY_F4_PROF
+// developer instrumentation (tools/f4prof.py): s_memtime stamps of chunk 5 of every tile and of the drain, per block
+__device__ unsigned long long f4_prof_buf[256 * 16];
+#endif
 
 struct Wino4Args {
   const float* X; const float* U; float* Y; const float* bias; double* stats;
@@ -56,39 +64,27 @@ __device__ __forceinline__ void mfma16_a(f32x4& c, float a, float b) {
 __device__ __forceinline__ void mfma16_v(f32x4& c, float a, float b) {
   asm volatile("v_mfma_f32_16x16x4_f32 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
-__device__ __forceinline__ f32x2 pkfma(f32x2 x, f32x2 y, f32x2 z) {           // x * y + z on both halves
-  f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-  return r;
-}
-__device__ __forceinline__ f32x2 pkfnma(f32x2 x, f32x2 y, f32x2 z) {          // z - x * y
-  f32x2 r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(x), "v"(y), "v"(z));
-  return r;
-}
-__device__ __forceinline__ f32x2 pkadd(f32x2 x, f32x2 y) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
-  return r;
-}
-__device__ __forceinline__ f32x2 pksub(f32x2 x, f32x2 y) {
-  f32x2 r;
-  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
-  return r;
-}
+// packed fp32 arithmetic as plain vector expressions: hipcc selects v_pk_fma_f32 / v_pk_add_f32 for them on gfx950 (with inline
+// constants and neg modifiers), and -- unlike inline-asm statements -- needs no s_nop pad between two dependent ones
+__device__ __forceinline__ f32x2 pkfma(f32x2 x, f32x2 y, f32x2 z) { return __builtin_elementwise_fma(x, y, z); }    // x * y + z
+__device__ __forceinline__ f32x2 pkfnma(f32x2 x, f32x2 y, f32x2 z) { return __builtin_elementwise_fma(-x, y, z); }  // z - x * y
+__device__ __forceinline__ f32x2 pkadd(f32x2 x, f32x2 y) { return x + y; }
+__device__ __forceinline__ f32x2 pksub(f32x2 x, f32x2 y) { return x - y; }
 // The B-operand ring is loaded and waited for by hand: tracked by hipcc, the loop header of the chunk loop waited vmcnt(0)
 // (the join of the loop's back edge with its entry), i.e. for the B loads issued in the chunk's last slots.  The counted
-// wait in front of a pair's first MFMA is a LOWER bound of the vector-memory operations younger than the pair's load
-// (at least 4 further ring loads; patch loads and output stores only add to them); hipcc's own vmcnt waits for the
-// patch loads stay correct, they count fewer younger operations than there are.
+// wait in front of a pair's first MFMA is the EXACT number of vector-memory operations the schedule issues between the
+// pair's load and that MFMA (f4_younger_b: with a flat vmcnt(4) the in-order counter made pair 2 wait for the patch loads
+// issued a few slots earlier, i.e. for HBM latency: the first third of a chunk took 2.3x its MFMA time); output stores of a
+// drain in between only add younger operations.
 template <int OFF> __device__ __forceinline__ void bload(f32x4& dst, const char* base, unsigned voff) {
   if constexpr (CY_F4_DBG & 4) dst = f32x4{1.f, 1.f, 1.f, 1.f};
   else asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(dst) : "v"(voff), "s"(base), "n"(OFF));
 }
-__device__ __forceinline__ void bwait4(f32x4& x) { asm volatile("s_waitcnt vmcnt(4)" : "+v"(x)); }
+template <int N> __device__ __forceinline__ void vmwait(f32x4& x) { asm volatile("s_waitcnt vmcnt(%1)" : "+v"(x) : "n"(N)); }
 // ... and so are the patch loads (a tracked load pending at the loop header draws the same vmcnt(0), which would then also
-// wait for the youngest ring loads).  A patch item is stored to LDS one chunk after its load: at least 10 vector-memory
-// operations are younger by then (first chunk of a block: 4 - q patch loads + 6 ring loads + q new patch loads; later 17+).
+// wait for the youngest ring loads).  A patch item is stored to LDS one chunk after its load; its wait counts the operations
+// younger than the load in the FIRST chunk of a block (f4_younger_r: 4 - q patch loads + the 6 ring loads of the prologue +
+// what the chunk has issued by then), fewer than in any later chunk.
 // The patch is read through a buffer descriptor of ONE image (base = the image, num_records = its bytes): a padding item
 // gets an offset beyond the image and the hardware's range check returns zeros -- no select, no zero page, no masks; the
 // chunk's channel offset travels as the instruction's scalar offset (no vector add per chunk).
@@ -99,7 +95,6 @@ __device__ __forceinline__ void rload(f32x4& dst, i32x4_ desc, unsigned voff, un
 #endif
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" CY_F4_RLOAD_AUX : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff));
 }
-__device__ __forceinline__ void rwait10(f32x4& x) { asm volatile("s_waitcnt vmcnt(10)" : "+v"(x)); }
 __device__ __forceinline__ void rwait0(f32x4& x) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(x)); }
 __device__ __forceinline__ float acc_elem4(float a_elem) {    // one accumulator element, read where the statement stands
   float x;
@@ -113,7 +108,7 @@ __device__ __forceinline__ float acc_elem4(float a_elem) {    // one accumulator
 //   1 G_B    B operand of position pair q + 6 (ring slot q % 6), right behind the last MFMA of pair q
 //   3 S_raw  one float4 of the patch of chunk f + 2: registers -> LDS        2 G_raw  one patch load of chunk f + 3
 //   4 T_rd   one column (7 float2) of the thread's patch of chunk f + 1      5 T_col  half a column of T = B^T d
-//   6 T_row  a quarter of one row of V = T B (2 + 4 + 4 + 2 FMAs, 1 + 2 + 2 + 1 LDS stores)
+//   6 T_row  a quarter of one row of V = T B (3 packed FMAs; the last two quarters store 3 positions each)
 //   7 ADV    patch cursor to f + 4
 struct F4Sched { int kind[144]; int idx[144]; };
 constexpr F4Sched f4_make_sched() {
@@ -147,6 +142,24 @@ constexpr bool f4_sched_ok() {                  // every piece placed exactly on
   return cnt[1] == 18 && cnt[2] == F4_NQ && cnt[3] == F4_NQ && cnt[4] == 6 && cnt[5] == 12 && cnt[6] == 12 && cnt[7] == 1;
 }
 static_assert(f4_sched_ok(), "winograd4: chunk schedule incomplete");
+// vector-memory operations (B ring loads, patch loads) the schedule issues in slots [lo, hi)
+constexpr int f4_vm_between(int lo, int hi) {
+  int n = 0;
+  for (int i = lo < 0 ? 0 : lo; i < hi && i < 144; ++i) n += (F4S.kind[i] == 1 || F4S.kind[i] == 2) ? 1 : 0;
+  return n;
+}
+constexpr int f4_slot_of(int kind, int idx) {
+  for (int i = 0; i < 144; ++i) if (F4S.kind[i] == kind && F4S.idx[i] == idx) return i;
+  return -1;
+}
+// operations younger than the load of position pair q when its first MFMA (slot 8 q) issues: the pair was loaded by G_B(q - 6)
+// of this chunk or G_B(q + 12) of the previous one (the prologue issues pairs 0..5 in the same order, behind its patch loads)
+constexpr int f4_younger_b(int q) {
+  return q >= F4_NBR ? f4_vm_between(f4_slot_of(1, q - F4_NBR) + 1, 8 * q)
+                     : f4_vm_between(f4_slot_of(1, q + 18 - F4_NBR) + 1, 144) + f4_vm_between(0, 8 * q);
+}
+// operations younger than the load of patch item q when S_raw(q) stores it, first chunk of a block (see rload)
+constexpr int f4_younger_r(int q) { return (F4_NQ - 1 - q) + F4_NBR + f4_vm_between(0, f4_slot_of(3, q)); }
 
 // EPI: 0 plain (input gradient), 1 BatchNorm statistics (training forward), 2 LeakyReLU (eval forward, BatchNorm folded)
 template <int EPI>
@@ -243,33 +256,41 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
     d[5] = *(const f32x2*)(rb + tbase + (3 * F4_PC + c) * 4);
     d[6] = *(const f32x2*)(rb + tbase + (4 * F4_PC + c) * 4);
   };
-  f32x2 cx_, cy_;
+  // Every piece holds mutually INDEPENDENT packed operations: gfx950 needs a wait state between a packed fp32 operation and a
+  // dependent one (hipcc pads with s_nop, an issue slot next to the MFMAs), so the dependent halves stand in later slots.
+  f32x2 cx_, cy_, ci_;
   auto Tcol = [&](int c, int part) {
     const f32x2* d = dc[c & 1];
     if (part == 0) {
       cx_ = pkfma(kal, d[4], d[6]);             // X = d4 + alpha d2
       cy_ = pkfma(kal, d[3], d[5]);             // Y = d3 + alpha d1
-      tt[1][c] = pkfma(kga, cy_, cx_);
+      ci_ = pkfma(km5, d[1], d[2]);
     } else {
+      tt[1][c] = pkfma(kga, cy_, cx_);
       tt[2][c] = pkfnma(kga, cy_, cx_);
-      tt[0][c] = pkfma(k4, d[0], pkfma(km5, d[1], d[2]));
+      tt[0][c] = pkfma(k4, d[0], ci_);
     }
   };
-  auto Trow = [&](float* vb, int r, int part) { // row r (of the thread's three), outputs j by part
+  f32x2 rt_[6];                                 // first halves of a row: i0, X1, Y1, X2, Y2, i5
+  auto Trow = [&](float* vb, int r, int part) { // row r (of the thread's three)
     const f32x2* x = tt[r];
     float* v = vb + (r == 0 ? vd0 : r == 1 ? vd1 : vd2);
     if (part == 0) {
-      *(f32x2*)(v + 0 * 256) = pkfma(k4, x[0], pkfma(km5, x[2], x[4]));
+      rt_[0] = pkfma(km5, x[2], x[4]);
+      rt_[1] = pkfma(km4, x[2], x[4]);
+      rt_[2] = pkfma(km4, x[1], x[3]);
     } else if (part == 1) {
-      const f32x2 X = pkfma(km4, x[2], x[4]), Y = pkfma(km4, x[1], x[3]);
-      *(f32x2*)(v + 1 * 256) = pkadd(X, Y);
-      *(f32x2*)(v + 2 * 256) = pksub(X, Y);
+      rt_[3] = pksub(x[4], x[2]);
+      rt_[4] = pksub(x[3], x[1]);
+      rt_[5] = pkfma(km5, x[3], x[5]);
     } else if (part == 2) {
-      const f32x2 X = pksub(x[4], x[2]), Y = pksub(x[3], x[1]);
-      *(f32x2*)(v + 3 * 256) = pkfma(k2, Y, X);
-      *(f32x2*)(v + 4 * 256) = pkfnma(k2, Y, X);
+      *(f32x2*)(v + 0 * 256) = pkfma(k4, x[0], rt_[0]);
+      *(f32x2*)(v + 1 * 256) = pkadd(rt_[1], rt_[2]);
+      *(f32x2*)(v + 2 * 256) = pksub(rt_[1], rt_[2]);
     } else {
-      *(f32x2*)(v + 5 * 256) = pkfma(k4, x[1], pkfma(km5, x[3], x[5]));
+      *(f32x2*)(v + 3 * 256) = pkfma(k2, rt_[4], rt_[3]);
+      *(f32x2*)(v + 4 * 256) = pkfnma(k2, rt_[4], rt_[3]);
+      *(f32x2*)(v + 5 * 256) = pkfma(k4, x[1], rt_[5]);
     }
   };
   auto Tall = [&](int buf_raw, int buf_v) {
@@ -316,8 +337,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
 #pragma unroll
   for (int q = 0; q < F4_NBR; ++q) {
     if (F4DBG & 4) bq[q] = f32x4{1.f, 1.f, 1.f, 1.f};
-    else if (q < 4) bload<0>(bq[q], up_cur + q * 1024, ulane[0]);
-    else bload<0>(bq[q], up_cur + (q - 4) * 1024, ulane[1]);
+    else bload<0>(bq[q], up_cur + (q & 3) * 1024, ulane[q >> 2]);
   }
 
   // A fragment of (position, tile half): 8 bytes at ((pos * 2 + half) * 4 + kgl) * 16 + (m ^ swizzle)
@@ -346,12 +366,21 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
       float* vw_ = Vs + ((c + 1) & 1) * F4_V_BUF;                 // ... and writes
       float* rw_ = Rs + (c & 1) * F4_RAW_BUF;                     // S_raw(f+2)
 #define F4_BARRIER_HERE if (s_ == F4_BAR) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#ifdef CY_F4_PROF
+      unsigned long long st_[8];
+      st_[0] = __builtin_amdgcn_s_memtime();
+#define F4_STAMP(s_) if ((s_) == 48) st_[1] = __builtin_amdgcn_s_memtime(); if ((s_) == 96) st_[2] = __builtin_amdgcn_s_memtime(); \
+                     if ((s_) == 136) st_[3] = __builtin_amdgcn_s_memtime(); if ((s_) == 137) st_[4] = __builtin_amdgcn_s_memtime();
+#else
+#define F4_STAMP(s_)
+#endif
 #define F4SLOT(SIDX)                                                                                  \
       {                                                                                               \
         constexpr int s_ = (SIDX), p_ = s_ >> 2, w_ = s_ & 3, h_ = w_ & 1, ks_ = w_ >> 1;             \
         constexpr int q_ = p_ >> 1, br_ = q_ % F4_NBR;                                                \
+        F4_STAMP(s_)                                                                                  \
         F4_BARRIER_HERE                                                                               \
-        if (w_ == 0 && (p_ & 1) == 0 && !(F4DBG & 4)) bwait4(bq[br_]);                                \
+        if (w_ == 0 && (p_ & 1) == 0 && !(F4DBG & 4)) vmwait<f4_younger_b(q_)>(bq[br_]);              \
         if (p_ < 32) mfma16_a(accA[p_ < 32 ? p_ : 0][h_], fa[p_ % 3][2 * h_ + ks_], bq[br_][2 * (p_ & 1) + ks_]); \
         else mfma16_v(accV[p_ >= 32 ? p_ - 32 : 0][h_], fa[p_ % 3][2 * h_ + ks_], bq[br_][2 * (p_ & 1) + ks_]);   \
         if (w_ == 0 && p_ + 2 < 36) {                                                                 \
@@ -369,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
           constexpr int lq_ = nq_ < 18 ? nq_ : nq_ - 18;                                              \
           bload<(lq_ & 3) * 1024>(bq[k_ % F4_NBR], nq_ < 18 ? up_cur : up_nxt, ulane[lq_ >> 2]);      \
         } else if (kind == 3) {                                                                       \
-          rwait10(graw[k_ % F4_NQ]);                                                                       \
+          vmwait<f4_younger_r(k_ % F4_NQ)>(graw[k_ % F4_NQ]);                                                                    \
           Sraw1(rw_, k_ % F4_NQ, graw[k_ % F4_NQ]);                                                         \
         } else if (kind == 2) {                                                                       \
           Graw1(k_ % F4_NQ, cr, graw[k_ % F4_NQ]);                                                                \
@@ -390,10 +419,24 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
 #undef F4SLOT8
 #undef F4SLOT
 #undef F4_BARRIER_HERE
+#undef F4_STAMP
+#ifdef CY_F4_PROF
+      st_[5] = __builtin_amdgcn_s_memtime();
+#endif
       up_cur = up_nxt;                          // U stream: positions f+1 / f+2
       if (advance(ku, cu)) {}
       up_nxt = u_ptr(ku, cu);
+#ifdef CY_F4_PROF
+      st_[6] = __builtin_amdgcn_s_memtime();
+      if (t == 0 && cm == 5 && km == 3) {
+        unsigned long long* pb = f4_prof_buf + blockIdx.x * 16;
+        for (int i = 0; i < 7; ++i) pb[i] = st_[i];
+      }
+#endif
     }
+#ifdef CY_F4_PROF
+    const unsigned long long dr0_ = __builtin_amdgcn_s_memtime();
+#endif
     // ======== tile km is complete: drain the accumulators.  V[cl&1] (cl = the tile's last position) was consumed and
     // is free until the barrier at the end of the drain: 9 KiB of it per wave are the drain's scratch.
     const int cl = c_next - 1;
@@ -541,7 +584,16 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
         atomicAdd(st + 2 * co + 1, (double)ssq);
       }
     }
+#ifdef CY_F4_PROF
+    const unsigned long long dr1_ = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();                            // the scratch is rewritten by the next position's transform
+#ifdef CY_F4_PROF
+    if (t == 0 && km == 3) {
+      unsigned long long* pb = f4_prof_buf + blockIdx.x * 16;
+      pb[8] = dr0_; pb[9] = dr1_; pb[10] = __builtin_amdgcn_s_memtime();
+    }
+#endif
   }
 }
 
@@ -635,3 +687,9 @@ extern "C" int cy_conv3x3_winograd4(const float* X, const float* U, float* Y, co
   CY_LAUNCH_CHECK("cy_conv3x3_winograd4");
   return 0;
 }
+
+#ifdef CY_F4_PROF
+extern "C" int cy_wino4_read_prof(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(f4_prof_buf), sizeof(unsigned long long) * 256 * 16);
+}
+#endif

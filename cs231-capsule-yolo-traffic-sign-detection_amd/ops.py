@@ -165,7 +165,7 @@ def _winograd(x, weight, bias, stats, transpose, tag, out_slope=1.0):
     u = _empty((query('cy_wino4_packed_floats' if f4 else 'cy_wino_packed_floats', Cg, n),), x)
     call('cy_wino4_pack_weights' if f4 else 'cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
     y = _empty((B, H, W_, n), x)
-    with timer.range(('conv_wino_dgrad/' if transpose else 'conv_wino_fwd/') + tag):
+    with timer.range(('conv_wino4_' if f4 else 'conv_wino_') + ('dgrad/' if transpose else 'fwd/') + tag):
         call('cy_conv3x3_winograd4' if f4 else 'cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats),
              float(out_slope), B, H, W_, Cg, n, st)
     return y

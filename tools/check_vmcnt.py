@@ -104,9 +104,9 @@ def check_kernel(name, body, max_steps=20000000):
                 if dst & touched:
                     errors[(pc - 1, at)] = '%s: line %d `%s` touches %s of the load at line %d, still in flight' % (
                         name[:60], pc - 1, body[pc - 1].strip(), sorted(dst & touched)[:2], at)
-            if mn.startswith('global_load') or mn.startswith('buffer_load'):
+            if mn.startswith('global_load') or mn.startswith('buffer_load') or mn.startswith('scratch_load'):
                 queue.append((frozenset(regs(ops[0])), pc - 1)); nloads.add(pc)
-            elif mn.startswith('global_store') or mn.startswith('global_atomic') or mn.startswith('buffer_store'):
+            elif mn.startswith('global_store') or mn.startswith('global_atomic') or mn.startswith('buffer_store') or mn.startswith('scratch_store'):
                 queue.append((frozenset(), -1))
             if len(queue) > 63:
                 queue.pop(0)                  # (the counter saturates; older operations have long retired)
