@@ -276,7 +276,7 @@ def routing_c43(dev, B, reps=5):
                               % (fwd_f / fwd_b, PEAK_FP32_MATRIX_TFLOPS * 1e3 / PEAK_HBM_GBPS)}
         del u, W
     out['note'] = ('launch_ms are HIP-event means over %d back-to-back calls (the CapsuleNet head is 6 short launches per '
-                   'forward: the bracket includes their gaps); per-kernel rocprof durations and PMC traffic: profiles/r02*' % reps)
+                   'forward: the bracket includes their gaps); per-kernel rocprof durations and PMC traffic: the newest set under profiles/' % reps)
     return out
 
 
