@@ -68,6 +68,8 @@ _SIGS = {
     'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_wino4_pack_weights': [_P, _P, _I, _I, _I, _P],
     'cy_conv3x3_winograd4': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    'cy_conv3x3_winograd4_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    'cy_conv3x3_winograd4_wgrad_bn': [_P, _P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd_wgrad_bn': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _L, _P, _P, _I, _I, _I, _I, _I, _P],
     'cy_bn_param_grad': [_P, _P, _P, _I, _P],
@@ -130,6 +132,8 @@ _RET = {
     'cy_conv_wgrad_bf16_ws_floats': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'cy_wino_packed_floats': (_L, [_I, _I]),
     'cy_wino4_packed_floats': (_L, [_I, _I]),
+    'cy_wino4_wgrad_ws_floats': (_L, [_I, _I, _I, _I, _I]),
+    'cy_wino4_wgrad_ok': (_I, [_I, _I, _I, _I, _I]),
     'cy_conv1_3x3_wgrad_ws_floats': (_L, [_I, _I, _I, _I]),
     'cy_conv1_3x3_stats_ws_floats': (_L, [_I, _I]),
     'cy_conv1_3x3_stats_m2_offset': (_L, [_I, _I]),

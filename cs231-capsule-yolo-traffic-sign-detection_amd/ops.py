@@ -319,12 +319,25 @@ def _wino_wgrad_ok(k, stride, pad, cin, cout):
     return USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and cin % 64 == 0 and cout % 64 == 0
 
 
+USE_WINOGRAD4_WGRAD = True   # the 3x3 layers' weight gradient on F(3x3,4x4) (winograd4_wgrad.hip) where its shape conditions hold and the
+                             # map has WINOGRAD4_MIN_PIXELS output pixels (below, the F(3x3,2x2) kernel)
+
+
+def _wino4_wgrad_ok(B, H, W, cin, cout):
+    return (USE_WINOGRAD4_WGRAD and B * H * W >= WINOGRAD4_MIN_PIXELS and bool(query('cy_wino4_wgrad_ok', B, H, W, cin, cout)))
+
+
 def conv_wgrad(x, dz, k, stride, pad, nchw=False, tag='conv', in_affine=None):
     x, dz = _f32(x, 'conv input'), _f32(dz, 'grad')
     B, Hi, Wi, Cin, xs = _x_geometry(x, nchw)
     _, Ho, Wo, Cout = dz.shape
     st = _stream()
     dW = _empty((Cout, Cin, k, k), dz)
+    if not nchw and USE_WINOGRAD and k == 3 and stride == 1 and pad == 1 and _wino4_wgrad_ok(B, Hi, Wi, Cin, Cout):
+        ws = _empty((query('cy_wino4_wgrad_ws_floats', B, Hi, Wi, Cin, Cout),), dz)
+        with timer.range('conv_wino4_wgrad/' + tag):
+            call('cy_conv3x3_winograd4_wgrad', _ptr(x), _ptr(dz), _ptr(dW), _ptr(ws), B, Hi, Wi, Cin, Cout, st)
+        return dW
     if not nchw and _wino_wgrad_ok(k, stride, pad, Cin, Cout):
         ws = _empty((query('cy_wino_wgrad_ws_floats', B, Cin, Cout),), dz)
         with timer.range('conv_wino_wgrad/' + tag):
@@ -613,11 +626,17 @@ class _ConvBlock(torch.autograd.Function):
                 call('cy_bn_param_grad', _ptr(red), _ptr(dgamma), _ptr(dbeta), N, st)
                 B_, Hi, Wi, Cin = x.shape
                 dW = _empty(tuple(weight.shape), z)
-                ws = _empty((query('cy_wino_wgrad_ws_floats', B_, Cin, N),), z)
-                with timer.range('conv_wino_wgrad_bn/' + cfg.name):
-                    call('cy_conv3x3_winograd_wgrad_bn', _ptr(_f32(x, 'conv input')), _ptr(z), _ptr(da), _ptr(dz), _ptr(scale),
-                         _ptr(shift), _ptr(mean), _ptr(invstd), slope, 1 if premasked else 0, _ptr(red), P, _ptr(dW), _ptr(ws),
-                         B_, Hi, Wi, Cin, N, st)
+                if premasked and _wino4_wgrad_ok(B_, Hi, Wi, Cin, N):
+                    ws = _empty((query('cy_wino4_wgrad_ws_floats', B_, Hi, Wi, Cin, N),), z)
+                    with timer.range('conv_wino4_wgrad_bn/' + cfg.name):
+                        call('cy_conv3x3_winograd4_wgrad_bn', _ptr(_f32(x, 'conv input')), _ptr(z), _ptr(da), _ptr(dz), _ptr(scale),
+                             _ptr(mean), _ptr(invstd), _ptr(red), P, _ptr(dW), _ptr(ws), B_, Hi, Wi, Cin, N, st)
+                else:
+                    ws = _empty((query('cy_wino_wgrad_ws_floats', B_, Cin, N),), z)
+                    with timer.range('conv_wino_wgrad_bn/' + cfg.name):
+                        call('cy_conv3x3_winograd_wgrad_bn', _ptr(_f32(x, 'conv input')), _ptr(z), _ptr(da), _ptr(dz), _ptr(scale),
+                             _ptr(shift), _ptr(mean), _ptr(invstd), slope, 1 if premasked else 0, _ptr(red), P, _ptr(dW), _ptr(ws),
+                             B_, Hi, Wi, Cin, N, st)
                 fused_wgrad = True
             else:
                 call('cy_bn_bwd_apply', _ptr(z), _ptr(da), _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),

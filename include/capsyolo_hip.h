@@ -161,6 +161,19 @@ long long cy_wino4_packed_floats(int Cin, int N);
 int cy_wino4_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
 int cy_conv3x3_winograd4(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
                          int B, int H, int W, int Cin, int Cout, void* stream);
+/* Weight gradient of the same layers through Winograd F(3x3,4x4) (36 multiplies per 4x4 tile of dZ and 3x3 taps: 1.78x fewer MFMAs
+ * than F(3x3,2x2) below; fp32 error ~6e-6 relative; replaces the weight-gradient half of nn.Conv2d backward, models.py:349-351).
+ * Shapes: cy_wino4_wgrad_ok (H % 4 == 0, W % 16 == 0, Cin % 32 == 0, Cout % 64 == 0, each image below 256 MB); ws:
+ * cy_wino4_wgrad_ws_floats floats.  _bn: as cy_conv3x3_winograd_wgrad_bn with a PREMASKED gradient (dA is d = dA lrelu'(y)):
+ * dz = d scale + (Z - mean) kb + kc is formed on the way in (kb, kc from red / count) and written to dZ for the input-gradient
+ * kernel. */
+int cy_wino4_wgrad_ok(int B, int H, int W, int Cin, int Cout);
+long long cy_wino4_wgrad_ws_floats(int B, int H, int W, int Cin, int Cout);
+int cy_conv3x3_winograd4_wgrad(const float* X, const float* dZ, float* dW, float* ws,
+                               int B, int H, int W, int Cin, int Cout, void* stream);
+int cy_conv3x3_winograd4_wgrad_bn(const float* X, const float* Z, const float* dA, float* dZ, const float* scale,
+                                  const float* mean, const float* invstd, const double* red, long long count,
+                                  float* dW, float* ws, int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through Winograd F(3x3,2x2): dW[Cout][Cin][3][3] from X[B][H][W][Cin] and
  * dZ[B][H][W][Cout] (replaces the weight-gradient half of nn.Conv2d backward, models.py:132-223 conv_2 class of
  * layers).  Cin % 64 == 0 and Cout % 64 == 0.  ws: cy_wino_wgrad_ws_floats(B, Cin, Cout) floats (Winograd-domain

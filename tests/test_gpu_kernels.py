@@ -1046,3 +1046,78 @@ def test_full_size_routing_head_matches_fp64_and_gather_is_address_only():
     vg = ops.routing(fh, W.to(dev()), 3, g, B)                             # [B, g, g, 1, 5]
     vp = v.detach().reshape(g, g, B, 1, Dout).permute(2, 0, 1, 3, 4)
     assert torch.equal(vg, vp.contiguous())
+
+
+@pytest.mark.parametrize('case', [(2, 32, 16, 16, 64), (1, 64, 4, 32, 128), (3, 32, 20, 48, 64), (2, 128, 8, 16, 256), (1, 32, 12, 16, 64),
+                                  (9, 64, 24, 48, 128)])
+def test_conv3x3_winograd4_wgrad_matches_fp64_and_f22(case, monkeypatch):
+    """Winograd F(3x3,4x4) weight gradient (winograd4_wgrad.hip: halo of the input patch at all four image borders, one-chunk-wide
+    and one-tile-row-high maps, several input- / output-channel blocks, tile ranges that cut through images) against torch fp64
+    and against the F(3x3,2x2) kernel.  Its transforms hold 4, 5, 8 and 1/24: 6e-6 relative to max against 1e-6 for F(3x3,2x2)
+    (tools/probe/wino_f34_wgrad_numerics.py), hence the bound of 5e-5."""
+    from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'WINOGRAD4_MIN_PIXELS', 0)
+    B, Cin, H, W_, Cout = case
+    x = rnd((B, Cin, H, W_), 81)
+    x = torch.where(x > 0, x, 0.1 * x)
+    w = rnd((Cout, Cin, 3, 3), 82, (1.0 / (Cin * 9)) ** 0.5)
+    wd = w.double().requires_grad_(True)
+    zr = F.conv2d(x.double(), wd, None, padding=1)
+    gz = rnd(tuple(zr.shape), 84)
+    zr.backward(gz.double())
+    xg = x.permute(0, 2, 3, 1).contiguous().to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        dw = ops.conv_wgrad(xg, gzd, 3, 1, 1, False, 'wg')
+    finally:
+        ops.timer.enabled = False
+    torch.cuda.synchronize()
+    assert 'conv_wino4_wgrad/wg' in ops.timer.summary()
+    scale = wd.grad.abs().max().item()
+    close(dw, wd.grad, 5e-5, 5e-5 * scale)
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_WGRAD', False)
+    dw2 = ops.conv_wgrad(xg, gzd, 3, 1, 1)
+    close(dw, dw2, 6e-5, 6e-5 * scale)
+
+
+@pytest.mark.parametrize('case', [(2, 32, 16, 32, 64, 0.0), (2, 64, 8, 16, 128, 3.0), (3, 128, 12, 48, 64, -1.0)])
+def test_conv3x3_winograd4_wgrad_with_fused_batchnorm_backward(case):
+    """cy_conv3x3_winograd4_wgrad_bn (premasked gradient: dz = d scale + (z - mean) kb + kc formed on the way in and written out
+    by the blocks of the first input-channel block) against cy_bn_bwd_apply + the F(3x3,2x2) weight gradient and the fp64 formula."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import call, query
+    B, Cin, H, W_, Cout, zmean = case
+    P = B * H * W_
+    x = rnd((B, H, W_, Cin), 171).to(dev())
+    z = (rnd((B, H, W_, Cout), 172) * 1.5 + zmean).to(dev())
+    d = rnd((B, H, W_, Cout), 173).to(dev())
+    gamma = (rnd((Cout,), 174).abs() + 0.5).to(dev())
+    zd = z.double().reshape(P, Cout)
+    mean, var = zd.mean(0), zd.var(0, unbiased=False)
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    scale = gamma.double() * invstd
+    dd = d.double().reshape(P, Cout)
+    xh = (zd - mean) * invstd
+    dz64 = scale * (dd - dd.mean(0) - xh * (dd * xh).mean(0))
+    f = lambda t: t.float().contiguous()
+    scale_f, mean_f, invstd_f = f(scale), f(mean), f(invstd)
+    red = torch.stack([dd.sum(0), (dd * xh).sum(0)], 1).contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    dz = torch.full_like(z, float('nan'))
+    dw = torch.empty(Cout, Cin, 3, 3, device=dev())
+    ws = torch.empty(query('cy_wino4_wgrad_ws_floats', B, H, W_, Cin, Cout), device=dev())
+    call('cy_conv3x3_winograd4_wgrad_bn', x.data_ptr(), z.data_ptr(), d.data_ptr(), dz.data_ptr(), scale_f.data_ptr(), mean_f.data_ptr(),
+         invstd_f.data_ptr(), red.data_ptr(), P, dw.data_ptr(), ws.data_ptr(), B, H, W_, Cin, Cout, st)
+    torch.cuda.synchronize()
+    assert torch.isfinite(dz).all()                                   # every element written
+    zs = dz64.abs().max().item()
+    close(dz.reshape(P, Cout), dz64, 1e-4, 0.0, 2e-5 * zs)
+    old = ops.USE_WINOGRAD4_WGRAD
+    try:
+        ops.USE_WINOGRAD4_WGRAD = False
+        dw_ref = ops.conv_wgrad(x, dz64.float().reshape(z.shape).contiguous(), 3, 1, 1)
+    finally:
+        ops.USE_WINOGRAD4_WGRAD = old
+    close(dw, dw_ref, 6e-5, 6e-5 * dw_ref.abs().max().item())
