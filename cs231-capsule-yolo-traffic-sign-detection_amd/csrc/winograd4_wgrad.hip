@@ -29,13 +29,24 @@ namespace {
 #define CY_G4_DBG 0
 #endif
 
-constexpr int G4_XPITCH = 40;                   // floats per raw input pixel: 32 channels + 8 pad (tile stride = 128 B mod 256)
+constexpr int G4_XPITCH = 36;                   // floats per raw input pixel: 32 channels + 4 pad; pixels stored COLUMN-major (col * 6 + row):
+                                                // a column's rows are 144 B apart (ds_read2_b64 pairs), a tile's 4 columns 128 B mod 256
 constexpr int G4_RAWX = 6 * 18 * G4_XPITCH;     // raw input patch
 constexpr int G4_RAWZ = 64 * 64;                // raw dz patch [4 x 16 pixels][64 channels]
 constexpr int G4_V_BUF = 18 * 4 * 16 * 4;       // [pos pair][tile][ci pair][pos in pair][ci parity]
 constexpr int G4_Z_BUF = 36 * 4 * 64;           // [pos][tile][co (bit 4 ^ tile parity)]
 
 typedef int i32x4g_ __attribute__((ext_vector_type(4)));
+#ifdef CY_G4_PROF
+// developer instrumentation (tools/g4prof.py): s_memtime stamps of one chunk per block and role
+__device__ unsigned long long g4_prof_buf[256 * 2 * 16];
+#define G4_STAMP(s_) { if ((s_) == 0) st_[0] = __builtin_amdgcn_s_memtime(); if ((s_) == 16) st_[1] = __builtin_amdgcn_s_memtime(); \
+                       if ((s_) == 31) st_[2] = __builtin_amdgcn_s_memtime(); if ((s_) == 32) st_[3] = __builtin_amdgcn_s_memtime(); \
+                       if ((s_) == 48) st_[4] = __builtin_amdgcn_s_memtime(); if ((s_) == 64) st_[5] = __builtin_amdgcn_s_memtime(); \
+                       if ((s_) == 65) st_[6] = __builtin_amdgcn_s_memtime(); }
+#else
+#define G4_STAMP(s_)
+#endif
 
 struct Wino4WgradArgs {
   const float* X; const float* dZ; float* slab;
@@ -74,34 +85,50 @@ __device__ __forceinline__ i32x4g_ g4_desc(const void* p, int bytes) {
 
 // ---- compile-time schedule of one chunk: 72 slots; slot s issues the MFMA of position s >> 1, input-channel half s & 1.
 // ROLE 0 (waves 0, 1): 6 T_rd + 12 T_col + 12 T_row pieces of the input transform; ROLE 1 (waves 2, 3): 4 Z_rd + 8 Z_col +
-// 12 Z_row pieces of the dz transform; then, for both: the mid barrier (every raw read of the chunk has returned), 8 S_raw
-// (one float4 of chunk f + 2: registers -> raw LDS) each followed by its G (the same register's load of chunk f + 3), the
-// cursor step, and the end barrier (slot 64) behind the last fragment read.
-constexpr int G4_MID = 31, G4_END = 64;
-constexpr int g4_kind(int role, int s) {        // 1 rd, 2 col, 3 row, 4 S_raw, 5 G, 6 ADV
-  const int nrd = role == 0 ? 6 : 4, ncol = role == 0 ? 12 : 8;
-  if (s < nrd + ncol + 12) {
-    if (role == 0) {                            // rd0 rd1 col0a col0b rd2 col1a col1b ... col5a col5b, then rows
-      if (s < 30 - 12) {
-        if (s < 2) return 1;
-        const int k = s - 2;                    // (col a, col b, rd) triples
-        if (k < 12) return (k % 3) == 2 ? 1 : 2;
-        return 2;
-      }
-      return 3;
-    }
-    return s < nrd ? 1 : s < nrd + ncol ? 2 : 3;
+// 12 Z_row pieces of the dz transform.  The raw reads (and the column passes that consume them) stand in front of the mid barrier
+// (slot 18), behind it 8 S_raw (one float4 of chunk f + 2: registers -> raw LDS), each followed by its G (the same register's load
+// of chunk f + 4), the row passes and the cursor step are spread over slots 19 .. 62 (packed into the first 31 slots the transform
+// ran at 2.2x its slots' MFMA time); the end barrier (slot 64) stands behind the last fragment read.
+constexpr int G4_MID = 18, G4_END = 64;
+struct G4Sched { int kind[72]; int idx[72]; };   // 1 rd, 2 col, 3 row, 4 S_raw, 5 G, 6 ADV
+constexpr G4Sched g4_make_sched(int role) {
+  G4Sched s{};
+  for (int i = 0; i < 72; ++i) { s.kind[i] = 0; s.idx[i] = 0; }
+  int pk[64] = {}, n = 0, sl = 0;
+  // in front of the mid barrier: every raw read (and what consumes it at once)
+  if (role == 0) {                              // rd0 rd1 c0a c0b rd2 c1a c1b rd3 ... rd5 c4a c4b c5a c5b
+    pk[n++] = 1; pk[n++] = 1;
+    for (int c = 0; c < 6; ++c) { pk[n++] = 2; pk[n++] = 2; if (c < 4) pk[n++] = 1; }
+  } else {                                      // rd0..3, the 8 column pieces, the first 6 row pieces
+    for (int i = 0; i < 4; ++i) pk[n++] = 1;
+    for (int i = 0; i < 8; ++i) pk[n++] = 2;
+    for (int i = 0; i < 6; ++i) pk[n++] = 3;
   }
-  if (s > G4_MID && s < G4_MID + 17) return ((s - G4_MID - 1) & 1) ? 5 : 4;
-  if (s == G4_MID + 17) return 6;
-  return 0;
+  for (int i = 0; i < n; ++i) s.kind[sl++] = pk[i];
+  // behind it (slots 19 .. 62): 8 x (S_raw, its G, a row piece), the remaining row pieces, the cursor step -- spread evenly
+  n = 0;
+  const int rows_left = role == 0 ? 12 : 6;
+  int r = 0;
+  for (int k = 0; k < 8; ++k) { pk[n++] = 4; pk[n++] = 5; if (r < rows_left) { pk[n++] = 3; ++r; } }
+  for (; r < rows_left; ++r) pk[n++] = 3;
+  pk[n++] = 6;
+  for (int i = 0; i < n; ++i) s.kind[G4_MID + 1 + (i * 44) / n] = pk[i];
+  int cnt[8] = {};
+  for (int i = 0; i < 72; ++i) { s.idx[i] = cnt[s.kind[i]]; cnt[s.kind[i]]++; }
+  return s;
 }
-constexpr int g4_idx(int role, int s) {
-  const int k = g4_kind(role, s);
-  int n = 0;
-  for (int i = 0; i < s; ++i) n += g4_kind(role, i) == k ? 1 : 0;
-  return n;
+constexpr G4Sched G4S0 = g4_make_sched(0), G4S1 = g4_make_sched(1);
+constexpr bool g4_sched_ok(const G4Sched& s, int role) {
+  int cnt[8] = {};
+  for (int i = 0; i < 72; ++i) cnt[s.kind[i]]++;
+  for (int i = 0; i <= G4_MID; ++i) if (s.kind[i] >= 4) return false;          // raw LDS is rewritten only behind the mid barrier
+  for (int i = G4_MID + 1; i < 72; ++i) if (s.kind[i] == 1) return false;       // ... and read only in front of it
+  for (int i = G4_END; i < 72; ++i) if (s.kind[i] != 0) return false;
+  return cnt[1] == (role == 0 ? 6 : 4) && cnt[2] == (role == 0 ? 12 : 8) && cnt[3] == 12 && cnt[4] == 8 && cnt[5] == 8 && cnt[6] == 1;
 }
+static_assert(g4_sched_ok(G4S0, 0) && g4_sched_ok(G4S1, 1), "winograd4_wgrad: chunk schedule incomplete");
+constexpr int g4_kind(int role, int s) { return role == 0 ? G4S0.kind[s] : G4S1.kind[s]; }
+constexpr int g4_idx(int role, int s) { return role == 0 ? G4S0.idx[s] : G4S1.idx[s]; }
 
 template <int BNF, int ROLE>
 __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
@@ -120,8 +147,14 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   const int jr = vid / (ncb * nib);
   const int ngroups = a.gh * a.gw;
   const long long gtot = (long long)a.B * ngroups;
-  const int cbeg = (int)(gtot * jr / a.nrange), cend = (int)(gtot * (jr + 1) / a.nrange);
-  const int nchunk = cend - cbeg;               // >= 1
+  // ranges are cut in chunk PAIRS (the loop body holds two chunks: static register sets and LDS buffers); a range whose last pair
+  // has no second chunk processes a phantom one whose input patch reads as zeros (V = 0: no contribution) and whose dz is not stored
+  const long long ptot = (gtot + 1) / 2;
+  const int pbeg = (int)(ptot * jr / a.nrange), pend = (int)(ptot * (jr + 1) / a.nrange);
+  const int cbeg = 2 * pbeg;
+  const int cend = 2 * pend < gtot ? 2 * pend : (int)gtot;
+  const int nchunk = cend - cbeg;               // >= 1 real chunks
+  const int npair = pend - pbeg;                // >= 1
 
   // ---- loaders.  Input patch: 864 float4 items (108 pixels x 8), item = t + 256 q: pixel = item >> 3, float4 = item & 7 (the 8
   // lanes of a pixel read its 128 contiguous bytes); the 4th round is partial (items of t >= 96 repeat their 3rd item).
@@ -136,14 +169,16 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
     const int pix = item >> 3, c4 = item & 7, pr = pix / 18, pc = pix - pr * 18;
     xvoff[q] = (unsigned)(((pr * a.W + pc) * a.Cin + cib * 32 + c4 * 4) * 4);
     xhfl[q] = (pr == 0 ? 1u << 28 : 0u) | (pr == 5 ? 1u << 29 : 0u) | (pc == 0 ? 1u << 30 : 0u) | (pc == 17 ? 1u << 31 : 0u);
-    xroff[q] = pix * G4_XPITCH + c4 * 4;
-    const int zi = t + 256 * q, zp = zi >> 4, zc = zi & 15;
+    xroff[q] = (pc * 6 + pr) * G4_XPITCH + c4 * 4;
+    // BNF == 4 (four input-channel blocks share a dz tile): the items are rotated by the block's index, so that item 0 -- one pixel
+    // row of the tile -- is the one this block writes back: one unconditional store per chunk, none for the other items
+    const int zi = t + 256 * (BNF == 4 ? ((q + cib) & 3) : q), zp = zi >> 4, zc = zi & 15;
     zvoff[q] = (unsigned)((((zp >> 4) * a.W + (zp & 15)) * a.Cout + cob * 64 + zc * 4) * 4);
     zroff[q] = zp * 64 + zc * 4;
     // the nib blocks that share a dz tile all form it; each of (at most four of) them writes a share of it: with ONE writer its four
     // stores per chunk sat in front of its own prefetch loads (vector-memory operations retire in order): +3.5 ms on the launch
     const int nsh = nib < 4 ? nib : 4;
-    zsto[q] = (cib < nsh && (q % nsh) == cib) ? zvoff[q] : 0x80000000u;
+    zsto[q] = BNF == 4 ? zvoff[q] : (cib < nsh && (q % nsh) == cib) ? zvoff[q] : 0x80000000u;
   }
   // chunk cursor of the loads (uniform): image, tile row, chunk column
   int lgb = 0, lty = 0, lcx = 0;
@@ -154,52 +189,67 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   int lrem = nchunk - 1;                        // chunks the cursor may still advance (it stops at the block's last chunk)
   i32x4g_ xdesc, zdesc, zzdesc, odesc;
   unsigned xsoff = 0, zsoff = 0, xbt = 0;
+  bool phantom = false;                         // the cursor stands behind the block's last real chunk
   auto set_cursor = [&]() {
-    xdesc = g4_desc((const char*)(a.X + (long long)lgb * a.H * a.W * a.Cin) - xshift, ximg_bytes + xshift);
+    xdesc = g4_desc((const char*)(a.X + (long long)lgb * a.H * a.W * a.Cin) - xshift, phantom ? 0 : ximg_bytes + xshift);
     zdesc = g4_desc(a.dZ + (long long)lgb * a.H * a.W * a.Cout, zimg_bytes);
     if constexpr (BNF) {
       zzdesc = g4_desc(a.Z + (long long)lgb * a.H * a.W * a.Cout, zimg_bytes);
-      odesc = g4_desc(a.dZout + (long long)lgb * a.H * a.W * a.Cout, zimg_bytes);
+      odesc = g4_desc(a.dZout + (long long)lgb * a.H * a.W * a.Cout, phantom ? 0 : zimg_bytes);
     }
     xsoff = (unsigned)(((4 * lty) * a.W + 16 * lcx) * a.Cin * 4);
     zsoff = (unsigned)(((4 * lty) * a.W + 16 * lcx) * a.Cout * 4);
     xbt = (lty == 0 ? 1u << 28 : 0u) | (lty == a.gh - 1 ? 1u << 29 : 0u) | (lcx == 0 ? 1u << 30 : 0u) | (lcx == a.gw - 1 ? 1u << 31 : 0u);
   };
   auto advance = [&]() {
-    if (lrem <= 0) return;
+    if (lrem <= 0) {
+      if (!phantom) { phantom = true; set_cursor(); }
+      return;
+    }
     --lrem;
     if (++lcx == a.gw) { lcx = 0; if (++lty == a.gh) { lty = 0; ++lgb; } }
     set_cursor();
   };
-  f32x4 gx[4], gz[4], zz[4];
-  unsigned osoff = 0;                           // BNF: scalar offset of the chunk held in gz / zz (its dz goes there)
-  i32x4g_ odesc_held;
-  auto Gx = [&](int q) { g4_load(gx[q], xdesc, (xhfl[q] & xbt) | xvoff[q], xsoff); };
-  auto Gz = [&](int q) {
-    g4_load(gz[q], zdesc, zvoff[q], zsoff);
-    if constexpr (BNF) { if (CY_G4_DBG & 2) zz[q] = gz[q]; else g4_load(zz[q], zzdesc, zvoff[q], zsoff); }
+  // two register sets: at the top of iteration f set f & 1 holds chunk f + 2 and the other set chunk f + 3, both possibly still in
+  // flight (a load has two chunks = 2 us to return: with one set -- 1 us -- the S_raw waits were the loop's largest stall)
+  f32x4 gx[2][4], gz[2][4], zz[2][4];
+  unsigned osoff[2] = {0u, 0u};                 // BNF: scalar offset / descriptor of the chunk held in set P (its dz goes there)
+  i32x4g_ odesc_held[2];
+  auto Gx = [&](int P, int q) { g4_load(gx[P][q], xdesc, (xhfl[q] & xbt) | xvoff[q], xsoff); };
+  auto Gz = [&](int P, int q) {
+    g4_load(gz[P][q], zdesc, zvoff[q], zsoff);
+    if constexpr (BNF) { if (CY_G4_DBG & 2) zz[P][q] = gz[P][q]; else g4_load(zz[P][q], zzdesc, zvoff[q], zsoff); }
   };
   // BNF: per-channel constants of this thread's 4 dz channels: dz = d * sc + (z - mu) * kb + kc
-  f32x4 k_sc = {0.f, 0.f, 0.f, 0.f}, k_nmu = k_sc, k_b = k_sc, k_c = k_sc;
+  // dz = d * sc + z * kb + kc with kc = -sc * mean(d) - mean * kb folded (two packed FMAs per channel pair)
+  f32x2 k2sc[2], k2b[2], k2c[2];
   if constexpr (BNF) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int ch = cob * 64 + (t & 15) * 4 + k;
       const float sc = a.scale[ch], is = a.invstd[ch];
       const float m1 = (float)(a.red[2 * ch] * a.inv_count), m2 = (float)(a.red[2 * ch + 1] * a.inv_count);
-      k_sc[k] = sc; k_nmu[k] = -a.mean[ch]; k_b[k] = -sc * is * m2; k_c[k] = -sc * m1;
+      const float kb = -sc * is * m2;
+      k2sc[k >> 1][k & 1] = sc; k2b[k >> 1][k & 1] = kb; k2c[k >> 1][k & 1] = __builtin_fmaf(-a.mean[ch], kb, -sc * m1);
     }
   }
-  auto Sx = [&](int q) { *(f32x4*)(Rx + xroff[q]) = gx[q]; };
-  auto Sz = [&](int q) {
+  auto Sx = [&](int P, int q) { *(f32x4*)(Rx + xroff[q]) = gx[P][q]; };
+  auto Sz = [&](int P, int q) {
     if constexpr (BNF) {
       f32x4 o;
+      if (CY_G4_DBG & 4) o = gz[P][q];
+      else {
 #pragma unroll
-      for (int k = 0; k < 4; ++k) o[k] = (CY_G4_DBG & 4) ? gz[q][k] : __builtin_fmaf(gz[q][k], k_sc[k], __builtin_fmaf(zz[q][k] + k_nmu[k], k_b[k], k_c[k]));
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 zv = {zz[P][q][2 * h], zz[P][q][2 * h + 1]}, dv = {gz[P][q][2 * h], gz[P][q][2 * h + 1]};
+          const f32x2 r = g4_fma(dv, k2sc[h], g4_fma(zv, k2b[h], k2c[h]));
+          o[2 * h] = r[0]; o[2 * h + 1] = r[1];
+        }
+      }
       *(f32x4*)(Rz + zroff[q]) = o;
-      if (!(CY_G4_DBG & 1)) g4_store(o, odesc_held, zsto[q], osoff);
+      if (!(CY_G4_DBG & 1) && (BNF != 4 || q == 0)) g4_store(o, odesc_held[P], zsto[q], osoff[P]);
     } else {
-      *(f32x4*)(Rz + zroff[q]) = gz[q];
+      *(f32x4*)(Rz + zroff[q]) = gz[P][q];
     }
   };
 
@@ -207,8 +257,8 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   // 2 r, 2 r + 1 as float2 (winograd4.hip: per-lane coefficients alpha / gamma and a row-shifted base make the halves one code)
   const int tt_ = t & 127;
   const int vr = tt_ & 15, vkg = (tt_ >> 4) & 3, hr = tt_ >> 6;
-  const int tbase = (4 * vkg) * G4_XPITCH + 2 * vr;
-  const int tbase_e = tbase + hr * 18 * G4_XPITCH;
+  const int tbase = (4 * vkg) * 6 * G4_XPITCH + 2 * vr;
+  const int tbase_e = tbase + hr * G4_XPITCH;
   const int vdst = (vkg * 16 + vr) * 4;
   const int vd0 = vdst + (hr ? 5 : 0) * 768, vd1 = vdst + (hr ? 3 : 1) * 768, vd2 = vdst + (hr ? 4 : 2) * 768;
   const float alpha_ = hr ? -1.f : -4.f, gamma_ = hr ? 2.f : 1.f;
@@ -217,13 +267,13 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   f32x2 tt[3][6], dc[2][7], cx_, cy_, ci_, rt_[6];
   auto Trd = [&](int c) {
     f32x2* d = dc[c & 1];
-    d[0] = *(const f32x2*)(Rx + tbase_e + (0 * 18 + c) * G4_XPITCH);
-    d[1] = *(const f32x2*)(Rx + tbase_e + (2 * 18 + c) * G4_XPITCH);
-    d[2] = *(const f32x2*)(Rx + tbase_e + (4 * 18 + c) * G4_XPITCH);
-    d[3] = *(const f32x2*)(Rx + tbase + (1 * 18 + c) * G4_XPITCH);
-    d[4] = *(const f32x2*)(Rx + tbase + (2 * 18 + c) * G4_XPITCH);
-    d[5] = *(const f32x2*)(Rx + tbase + (3 * 18 + c) * G4_XPITCH);
-    d[6] = *(const f32x2*)(Rx + tbase + (4 * 18 + c) * G4_XPITCH);
+    d[0] = *(const f32x2*)(Rx + tbase_e + (c * 6 + 0) * G4_XPITCH);
+    d[1] = *(const f32x2*)(Rx + tbase_e + (c * 6 + 2) * G4_XPITCH);
+    d[2] = *(const f32x2*)(Rx + tbase_e + (c * 6 + 4) * G4_XPITCH);
+    d[3] = *(const f32x2*)(Rx + tbase + (c * 6 + 1) * G4_XPITCH);
+    d[4] = *(const f32x2*)(Rx + tbase + (c * 6 + 2) * G4_XPITCH);
+    d[5] = *(const f32x2*)(Rx + tbase + (c * 6 + 3) * G4_XPITCH);
+    d[6] = *(const f32x2*)(Rx + tbase + (c * 6 + 4) * G4_XPITCH);
   };
   auto Tcol = [&](int c, int part) {
     const f32x2* d = dc[c & 1];
@@ -319,40 +369,37 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
     }
   };
 
-  // ---- prologue.  State at the top of iteration f: V / Z[f&1] = chunk f, raw LDS = chunk f + 1, registers = chunk f + 2 (in
-  // flight), load cursor at f + 3.
+  // ---- prologue.  State at the top of iteration f (P = f & 1): V / Z[P] = chunk f, raw LDS = chunk f + 1, register set P = chunk
+  // f + 2, set 1 - P = chunk f + 3, load cursor at f + 4.  Every round issues its loads in the loop's order (Gx0..3, Gz0..3): the
+  // loop's hand-counted waits hold for its first iterations too.
+  auto Gall = [&](int P) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Gx(P, q);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Gz(P, q);
+    if constexpr (BNF) { osoff[P] = zsoff; odesc_held[P] = odesc; }
+    advance();
+  };
+  auto Wall = [&](int P) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { g4_vmwait<0>(gx[P][q]); g4_vmwait<0>(gz[P][q]); if constexpr (BNF) g4_vmwait<0>(zz[P][q]); }
+  };
+  auto Sall = [&](int P) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { Sx(P, q); Sz(P, q); }
+  };
   set_cursor();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gx(q);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gz(q);
-  if constexpr (BNF) { osoff = zsoff; odesc_held = odesc; }
-  advance();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { g4_vmwait<0>(gx[q]); g4_vmwait<0>(gz[q]); if constexpr (BNF) g4_vmwait<0>(zz[q]); }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { Sx(q); Sz(q); }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gx(q);
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gz(q);
-  const unsigned osoff1 = zsoff;
-  const i32x4g_ odesc1 = odesc;
-  advance();
+  Gall(0);                                      // chunk 0
+  Wall(0);
+  Sall(0);
+  Gall(1);                                      // chunk 1
   __syncthreads();
   Tall(0);
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { g4_vmwait<0>(gx[q]); g4_vmwait<0>(gz[q]); if constexpr (BNF) g4_vmwait<0>(zz[q]); }
-  if constexpr (BNF) { osoff = osoff1; odesc_held = odesc1; }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) { Sx(q); Sz(q); }
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gx(q);                 // (the loop's issue order: its hand-counted waits hold for iteration 0 too)
-#pragma unroll
-  for (int q = 0; q < 4; ++q) Gz(q);
-  if constexpr (BNF) { osoff = zsoff; odesc_held = odesc; }
-  advance();
+  Wall(1);
+  Sall(1);
+  Gall(0);                                      // chunk 2
+  Gall(1);                                      // chunk 3
   __syncthreads();
 
   // fragments: A of position pair q: 16 bytes at ((q * 4 + kgl) * 16 + ml) * 4; B of position p: ((p * 4 + kgl) * 64 + col)
@@ -360,11 +407,12 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   const int fragA = (kgl * 16 + ml) * 4;
   const int fragB = kgl * 64 + ((16 * wave + ml) ^ ((kgl & 1) << 4));
   f32x4 fa[3];
-  float fb[6];
+  f32x2 fb[3];                                  // B fragments of position pairs (two dwords 1 KiB apart: one ds_read2st64_b32)
+  auto rdB = [&](const float* zp) { return f32x2{zp[0], zp[256]}; };
   fa[0] = *(const f32x4*)(Vs + fragA);
   fa[1] = *(const f32x4*)(Vs + fragA + 256);
-#pragma unroll
-  for (int p = 0; p < 4; ++p) fb[p] = Zs[fragB + p * 256];
+  fb[0] = rdB(Zs + fragB);
+  fb[1] = rdB(Zs + fragB + 512);
 
   f32x4 accA[32][2], accV[4][2];
 #pragma unroll
@@ -376,32 +424,40 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) accV[p][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // vector-memory operations per iteration, in issue order: Gx0..3, then per dz item [dz store (BNF)], Gz, [Gzz (BNF)]; the prologue
-  // issues its last round in the same order (without the stores).  S_raw(q) of iteration f + 1 waits for the load of iteration f
-  // into the same register: exactly 7 younger operations without BNF; with BNF at least 10 (iteration 0: 11 for the x items,
-  // 11 + q for d, 10 + q for z; later iterations 15 / 14 / 13) -- a lower bound of the younger operations is what a wait needs
-  constexpr int VMW = BNF ? 10 : 7;
-  for (int f = 0; f < nchunk; ++f) {
-    const float* va_ = Vs + (f & 1) * G4_V_BUF + fragA;
-    const float* zb_ = Zs + (f & 1) * G4_Z_BUF + fragB;
-    float* vw_ = Vs + ((f + 1) & 1) * G4_V_BUF;
-    float* zw_ = Zs + ((f + 1) & 1) * G4_Z_BUF;
+  // vector-memory operations per iteration, in issue order: Gx0..3, then per dz item [dz store (BNF)], Gz, [Gzz (BNF)].  S_raw(q) of
+  // iteration f waits for the load of iteration f - 2 into the same register: exactly 15 younger operations without BNF; with BNF
+  // at least 22 (iteration 0, whose loads the prologue issued without stores: 23 for the x items, 23 + q for d, 22 + q for z; later
+  // 31 / 30 / 29) -- a lower bound of the younger operations is what a wait needs
+  // (BNF == 4: one store per iteration: 13 operations per iteration, at least 22 younger ones as well)
+  constexpr int VMW = BNF ? 22 : 15;
+#ifdef CY_G4_PROF
+  unsigned long long st_[8];
+#endif
+  for (int f = 0; f < npair; ++f) {
+#define G4CHUNK(PAR)                                                                                  \
+  {                                                                                                   \
+    constexpr int P_ = (PAR);                                                                         \
+    const float* va_ = Vs + P_ * G4_V_BUF + fragA;                                                    \
+    const float* zb_ = Zs + P_ * G4_Z_BUF + fragB;                                                    \
+    float* vw_ = Vs + (1 - P_) * G4_V_BUF;                                                            \
+    float* zw_ = Zs + (1 - P_) * G4_Z_BUF;                                                            \
+    G4SLOT8(0) G4SLOT8(8) G4SLOT8(16) G4SLOT8(24) G4SLOT8(32) G4SLOT8(40) G4SLOT8(48) G4SLOT8(56) G4SLOT8(64) \
+  }
 #define G4SLOT(SIDX)                                                                                  \
     {                                                                                                 \
       constexpr int s_ = (SIDX), p_ = s_ >> 1, mt_ = s_ & 1, q_ = p_ >> 1;                            \
+      G4_STAMP(s_)                                                                                    \
       if (s_ == G4_MID || s_ == G4_END) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
-      if (p_ < 32) g4_mfma_a(accA[p_ < 32 ? p_ : 0][mt_], fa[q_ % 3][2 * (p_ & 1) + mt_], fb[p_ % 6]); \
-      else g4_mfma_v(accV[p_ >= 32 ? p_ - 32 : 0][mt_], fa[q_ % 3][2 * (p_ & 1) + mt_], fb[p_ % 6]);   \
+      if (p_ < 32) g4_mfma_a(accA[p_ < 32 ? p_ : 0][mt_], fa[q_ % 3][2 * (p_ & 1) + mt_], fb[q_ % 3][p_ & 1]); \
+      else g4_mfma_v(accV[p_ >= 32 ? p_ - 32 : 0][mt_], fa[q_ % 3][2 * (p_ & 1) + mt_], fb[q_ % 3][p_ & 1]);   \
       if (s_ < G4_END) {                                                                              \
-        if ((s_ & 3) == 0 && q_ + 2 < 18) fa[(q_ + 2) % 3] = *(const f32x4*)(va_ + (q_ + 2) * 256);   \
-        if (mt_ == 0 && p_ + 4 < 36) fb[(p_ + 4) % 6] = zb_[(p_ + 4) * 256];                          \
-      } else {                                  /* behind the end barrier: the next chunk's first fragments */ \
-        if (s_ == 64) fa[0] = *(const f32x4*)(vw_ + fragA);                                           \
-        if (s_ == 68) fa[1] = *(const f32x4*)(vw_ + fragA + 256);                                     \
-        if (s_ == 64) fb[0] = zw_[fragB];                                                             \
-        if (s_ == 65) fb[1] = zw_[fragB + 256];                                                       \
-        if (s_ == 66) fb[2] = zw_[fragB + 512];                                                       \
-        if (s_ == 68) fb[3] = zw_[fragB + 768];                                                       \
+        if ((s_ & 3) == 0 && q_ + 2 < 18) {                                                           \
+          fa[(q_ + 2) % 3] = *(const f32x4*)(va_ + (q_ + 2) * 256);                                   \
+          fb[(q_ + 2) % 3] = rdB(zb_ + (q_ + 2) * 512);                                               \
+        }                                                                                             \
+      } else {                                  /* behind the end barrier: the next chunk's first fragments (ring slot 0 is free at slot 64, slot 1 at 68) */ \
+        if (s_ == 64) { fa[0] = *(const f32x4*)(vw_ + fragA); fb[0] = rdB(zw_ + fragB); }             \
+        if (s_ == 68) { fa[1] = *(const f32x4*)(vw_ + fragA + 256); fb[1] = rdB(zw_ + fragB + 512); } \
       }                                                                                               \
       constexpr int kind = g4_kind(ROLE, s_), k_ = g4_idx(ROLE, s_);                                  \
       if (kind == 1) {                                                                                \
@@ -411,26 +467,37 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
       } else if (kind == 3) {                                                                         \
         if constexpr (ROLE == 0) Trow(vw_, (k_ >> 2) % 3, k_ & 3); else Zrow(zw_, (k_ >> 1) % 6, k_ & 1); \
       } else if (kind == 4) {                   /* S_raw: x items 0..3, then dz items 0..3 */        \
-        if (k_ < 4) { g4_vmwait<VMW>(gx[k_ & 3]); Sx(k_ & 3); }                                       \
-        else { g4_vmwait<VMW>(gz[k_ & 3]); if constexpr (BNF) g4_vmwait<VMW>(zz[k_ & 3]); Sz(k_ & 3); } \
+        if (k_ < 4) { g4_vmwait<VMW>(gx[P_][k_ & 3]); Sx(P_, k_ & 3); }                               \
+        else { g4_vmwait<VMW>(gz[P_][k_ & 3]); if constexpr (BNF) g4_vmwait<VMW>(zz[P_][k_ & 3]); Sz(P_, k_ & 3); } \
       } else if (kind == 5) {                                                                         \
-        if (k_ < 4) Gx(k_ & 3); else Gz(k_ & 3);                                                      \
+        if (k_ < 4) Gx(P_, k_ & 3); else Gz(P_, k_ & 3);                                              \
       } else if (kind == 6) {                                                                         \
-        if constexpr (BNF) { osoff = zsoff; odesc_held = odesc; }                                     \
+        if constexpr (BNF) { osoff[P_] = zsoff; odesc_held[P_] = odesc; }                             \
         advance();                                                                                    \
       }                                                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                              \
     }
 #define G4SLOT8(B) G4SLOT((B)) G4SLOT((B) + 1) G4SLOT((B) + 2) G4SLOT((B) + 3) G4SLOT((B) + 4) G4SLOT((B) + 5) G4SLOT((B) + 6) G4SLOT((B) + 7)
-    G4SLOT8(0) G4SLOT8(8) G4SLOT8(16) G4SLOT8(24) G4SLOT8(32) G4SLOT8(40) G4SLOT8(48) G4SLOT8(56) G4SLOT8(64)
+    G4CHUNK(0)
+#ifdef CY_G4_PROF
+    st_[7] = __builtin_amdgcn_s_memtime();
+    if ((t & 127) == 0 && f == 7) {
+      unsigned long long* pb = g4_prof_buf + (blockIdx.x * 2 + ROLE) * 16;
+      for (int i = 0; i < 8; ++i) pb[i] = st_[i];
+    }
+#endif
+    G4CHUNK(1)
 #undef G4SLOT8
 #undef G4SLOT
+#undef G4CHUNK
   }
 
   // the loads of the chunks behind the block's last one are still in flight and hipcc does not know: their registers must not be
   // reused before they have landed
 #pragma unroll
-  for (int q = 0; q < 4; ++q) { g4_vmwait<0>(gx[q]); g4_vmwait<0>(gz[q]); if constexpr (BNF) g4_vmwait<0>(zz[q]); }
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int P = 0; P < 2; ++P) { g4_vmwait<0>(gx[P][q]); g4_vmwait<0>(gz[P][q]); if constexpr (BNF) g4_vmwait<0>(zz[P][q]); }
   // ---- the block's partial sums: slab[range][pos][ci][co]; lane l, register e of accumulator (pos, mt): ci pair 4 (l >> 4) + e
   float* sl = a.slab + ((long long)jr * 36 * a.Cin + cib * 32) * a.Cout + cob * 64 + 16 * wave + ml;
 #pragma unroll
@@ -485,7 +552,7 @@ __global__ void wino4_wgrad_finish_kernel(const float* __restrict__ slab, float*
 int g4_nrange(int B, int H, int W, int Cin, int Cout) {
   int dev = 0, ncu = 256;
   if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-  const long long tiles = (long long)B * (H / 4) * (W / 16);
+  const long long tiles = ((long long)B * (H / 4) * (W / 16) + 1) / 2;   // chunk pairs
   const int per = (Cin / 32) * (Cout / 64);
   long long n = ncu / per;
   if (const char* e = getenv("CY_G4_NRANGE")) n = atoll(e);            // developer override (tests of the range logic)
@@ -514,7 +581,10 @@ static int g4_launch(Wino4WgradArgs& a, float* dW, bool bnf, hipStream_t s) {
   if (rc) return rc;
   rc = cy_allow_lds(wino4_wgrad_kernel<1>, lds);
   if (rc) return rc;
-  if (bnf) wino4_wgrad_kernel<1><<<(unsigned)blocks, 256, lds, s>>>(a);
+  rc = cy_allow_lds(wino4_wgrad_kernel<4>, lds);
+  if (rc) return rc;
+  if (bnf && a.Cin == 128) wino4_wgrad_kernel<4><<<(unsigned)blocks, 256, lds, s>>>(a);   // four input-channel blocks: one dz row each
+  else if (bnf) wino4_wgrad_kernel<1><<<(unsigned)blocks, 256, lds, s>>>(a);
   else wino4_wgrad_kernel<0><<<(unsigned)blocks, 256, lds, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd4_wgrad");
   const int n = a.Cin * a.Cout;
@@ -545,3 +615,9 @@ extern "C" int cy_conv3x3_winograd4_wgrad_bn(const float* X, const float* Z, con
   a.Z = Z; a.dZout = dZ; a.scale = scale; a.mean = mean; a.invstd = invstd; a.red = red; a.inv_count = 1.0 / (double)count;
   return g4_launch(a, dW, true, (hipStream_t)stream);
 }
+
+#ifdef CY_G4_PROF
+extern "C" int cy_wino4_wgrad_read_prof(unsigned long long* host_dst) {
+  return (int)hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(g4_prof_buf), sizeof(unsigned long long) * 256 * 2 * 16);
+}
+#endif

@@ -1082,7 +1082,7 @@ def test_conv3x3_winograd4_wgrad_matches_fp64_and_f22(case, monkeypatch):
     close(dw, dw2, 6e-5, 6e-5 * scale)
 
 
-@pytest.mark.parametrize('case', [(2, 32, 16, 32, 64, 0.0), (2, 64, 8, 16, 128, 3.0), (3, 128, 12, 48, 64, -1.0)])
+@pytest.mark.parametrize('case', [(2, 32, 16, 32, 64, 0.0), (2, 64, 8, 16, 128, 3.0), (3, 128, 12, 48, 64, -1.0), (5, 128, 24, 32, 128, 2.0)])
 def test_conv3x3_winograd4_wgrad_with_fused_batchnorm_backward(case):
     """cy_conv3x3_winograd4_wgrad_bn (premasked gradient: dz = d scale + (z - mean) kb + kc formed on the way in and written out
     by the blocks of the first input-channel block) against cy_bn_bwd_apply + the F(3x3,2x2) weight gradient and the fp64 formula."""
