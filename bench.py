@@ -328,6 +328,7 @@ _KIND_PEAKS = {   # timer key prefix -> (issued / direct-convolution FLOPs, MFMA
     'conv_wino_fwd': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino_dgrad': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino4_fwd': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino4_dgrad': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino_wgrad': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino_wgrad_bn': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS),
+    'conv_wino4_wgrad': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino4_wgrad_bn': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_fwd': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino2_dgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_wgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_gemm_fwd': (1.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wgrad': (1.0, PEAK_FP32_MATRIX_TFLOPS),
@@ -517,6 +518,8 @@ def main():
                 ('conv_gemm_fwd/conv_2', 'conv_gemm_kernel<2,true> (conv_2 forward, implicit GEMM, fp32 MFMA)', 1.0),
                 ('conv_wino_dgrad/conv_2', 'wino_conv_kernel (conv_2 input gradient, fused Winograd F(2x2,3x3))', 1 / 2.25),
                 ('conv_gemm_dgrad/conv_2', 'conv_gemm_kernel<2,true> (conv_2 input gradient, implicit GEMM)', 1.0),
+                ('conv_wino4_wgrad/conv_2', 'wino4_wgrad_kernel<0> + finish (conv_2 weight gradient, fused Winograd F(3x3,4x4) on v_mfma_f32_16x16x4_f32)', 1 / 4.0),
+                ('conv_wino4_wgrad_bn/conv_2', 'wino4_wgrad_kernel<4> + finish (conv_2 weight gradient, fused Winograd F(3x3,4x4), with the block\'s BatchNorm backward pass 2 applied to the premasked gradient on the way in and dz written for the input-gradient kernel)', 1 / 4.0),
                 ('conv_wino_wgrad/conv_2', 'wino_wgrad_kernel + finish (conv_2 weight gradient, fused Winograd F(3x3,2x2))', 1 / 2.25),
                 ('conv_wino_wgrad_bn/conv_2', 'wino_wgrad_kernel<2> + finish (conv_2 weight gradient, fused Winograd F(3x3,2x2), with the block\'s BatchNorm backward pass 2 applied to the (premasked) gradient on the way in and dz written for the input-gradient kernel)', 1 / 2.25),
                 ('conv_wgrad/conv_2', 'conv_wgrad_kernel<2,2,2,2,true> + wgrad_reduce_kernel (conv_2 weight gradient, fp32 MFMA)', 1.0),
@@ -542,7 +545,7 @@ def main():
                                                  if tr else None),
                               'launch_ms': round(ms, 4), 'launches_timed': n,
                               'note': 'achieved = issued MFMA FLOPs (direct-convolution 2*M*N*K = %.3f TFLOP with M=%d, N=256, '
-                                      'K=1152, / 2.25 for the F(2x2,3x3) / F(3x3,2x2) Winograd kernels, / 4 for F(4x4,3x3)) / mean launch time; '
+                                      'K=1152, / 2.25 for the F(2x2,3x3) / F(3x3,2x2) Winograd kernels, / 4 for F(4x4,3x3) / F(3x3,4x4)) / mean launch time; '
                                       'effective_vs_direct = direct-convolution FLOPs / time / peak' % (conv2_flops / 1e12, M)})
         cands.sort(key=lambda d: -d['launch_ms'])
         R = g * g * B

@@ -53,5 +53,20 @@ for (Cin, H, Cout, k, s) in ((128, 208, 256, 3, 1), (256, 208, 64, 4, 2), (64, 1
                  mu.data_ptr(), isd.data_ptr(), 0.1, 0, red.data_ptr(), B * Ho * Ho, dw.data_ptr(), ws.data_ptr(), B, H, H, Cin, Cout, st)
             return torch.cat([o.flatten(), dw.flatten()])
         rep(tag + 'fp32 wgrad + BatchNorm pass 2 (dz, dW)', fused)
+        if query('cy_wino4_wgrad_ok', B, H, H, Cin, Cout):
+            ws4 = torch.empty(query('cy_wino4_wgrad_ws_floats', B, H, H, Cin, Cout), device=dev)
+
+            def fused4():
+                o, dw = torch.empty_like(z), torch.empty(Cout, Cin, 3, 3, device=dev)
+                call('cy_conv3x3_winograd4_wgrad_bn', x.data_ptr(), z.data_ptr(), dz.data_ptr(), o.data_ptr(), sc.data_ptr(), mu.data_ptr(),
+                     isd.data_ptr(), red.data_ptr(), B * Ho * Ho, dw.data_ptr(), ws4.data_ptr(), B, H, H, Cin, Cout, st)
+                return torch.cat([o.flatten(), dw.flatten()])
+            rep(tag + 'fp32 F(3x3,4x4) wgrad + BatchNorm pass 2 (dz, dW)', fused4)
+            old = ops.WINOGRAD4_MIN_PIXELS
+            ops.WINOGRAD4_MIN_PIXELS = 0
+            rep(tag + 'fp32 F(3x3,4x4) wgrad', lambda: ops.conv_wgrad(x, dz, k, s, 1))
+            rep(tag + 'fp32 F(4x4,3x3) fwd', lambda: ops.conv_forward(x, w, b, k, s, 1))
+            rep(tag + 'fp32 F(4x4,3x3) dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), k, s, 1))
+            ops.WINOGRAD4_MIN_PIXELS = old
 print('check_determinism:', 'ok' if bad == 0 else 'FAILED')
 sys.exit(0 if bad == 0 else 1)

@@ -28,6 +28,8 @@ pick = {
     'conv_wino_dgrad/conv_2': ('wino_conv_kernel<0>', -1),
     'conv_wino4_fwd/conv_2': ('wino4_conv_kernel<1>', -1),
     'conv_wino4_dgrad/conv_2': ('wino4_conv_kernel<0>', -1),
+    'conv_wino4_wgrad/conv_2': ('wino4_wgrad_kernel<0>', -1),
+    'conv_wino4_wgrad_bn/conv_2': ('wino4_wgrad_kernel<4>', -1),
     'conv_wino_wgrad/conv_2': ('wino_wgrad_kernel<0>', 1),
     'conv_wino_wgrad_bn/conv_2': ('wino_wgrad_kernel<2>', -1),    # (premasked gradient, as in the training step)
     'routing_fwd': ('caps1_fwd_kernel<5, true>', -1),

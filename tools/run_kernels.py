@@ -52,7 +52,11 @@ if what in ('conv2', 'all'):
     timeit('conv2 wgrad + bn pass 2', lambda: call('cy_conv3x3_winograd_wgrad_bn', x.data_ptr(), z2.data_ptr(), dz.data_ptr(), dzo.data_ptr(),
                                                    sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1.0, 1, red.data_ptr(), B * H * H,
                                                    dW.data_ptr(), ws.data_ptr(), B, H, H, 128, 256, st), fl)
-    del z2, dzo
+    ws4 = torch.empty(query('cy_wino4_wgrad_ws_floats', B, H, H, 128, 256), device=dev)
+    timeit('conv2 wgrad F(3x3,4x4) + bn pass 2', lambda: call('cy_conv3x3_winograd4_wgrad_bn', x.data_ptr(), z2.data_ptr(), dz.data_ptr(), dzo.data_ptr(),
+                                                              sc.data_ptr(), mu.data_ptr(), isd.data_ptr(), red.data_ptr(), B * H * H,
+                                                              dW.data_ptr(), ws4.data_ptr(), B, H, H, 128, 256, st), fl)
+    del z2, dzo, ws4
     del x, dz
 if what in ('conv3', 'all'):
     H = 416
