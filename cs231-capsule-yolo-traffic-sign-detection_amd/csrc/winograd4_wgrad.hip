@@ -518,8 +518,19 @@ __global__ __launch_bounds__(256, 1) void wino4_wgrad_kernel(Wino4WgradArgs a) {
   else g4_run<BNF, 1>(a, smem);
 }
 
-// dW[co][ci][3][3] = A^T [ S (sum_ranges dU) S ] A with S = diag(1/4, -1/6, -1/6, 1/24, 1/24, 1), A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,1]]
-__global__ void wino4_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dW, int nrange, int Cin, int Cout) {
+// sum of the ranges' partial sums, in range order (deterministic), into the slab of range 0: one thread per (pos, ci, co) -- a layer
+// with few channels has few (ci, co) pairs but many ranges (DarkNet conv_2: 2048 pairs x 256 ranges), so the sum over the ranges
+// must not sit in the per-pair finish kernel
+__global__ void wino4_wgrad_reduce_kernel(float* __restrict__ slab, int nrange, long long per_range) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= per_range) return;
+  float s = slab[idx];
+  for (int r = 1; r < nrange; ++r) s += slab[(long long)r * per_range + idx];
+  slab[idx] = s;
+}
+
+// dW[co][ci][3][3] = A^T [ S dU S ] A with S = diag(1/4, -1/6, -1/6, 1/24, 1/24, 1), A^T = [[1,1,1,1,1,0],[0,1,-1,2,-2,0],[0,1,1,4,4,1]]
+__global__ void wino4_wgrad_finish_kernel(const float* __restrict__ slab, float* __restrict__ dW, int Cin, int Cout) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Cin * Cout) return;
   const int co = idx % Cout, ci = idx / Cout;
@@ -528,11 +539,7 @@ __global__ void wino4_wgrad_finish_kernel(const float* __restrict__ slab, float*
 #pragma unroll
   for (int i = 0; i < 6; ++i)
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      float s = 0.f;
-      for (int r = 0; r < nrange; ++r) s += slab[(((long long)r * 36 + (6 * i + j)) * Cin + ci) * Cout + co];
-      m[i][j] = s * (sc[i] * sc[j]);
-    }
+    for (int j = 0; j < 6; ++j) m[i][j] = slab[((long long)(6 * i + j) * Cin + ci) * Cout + co] * (sc[i] * sc[j]);
   float sr[6][3];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
@@ -588,7 +595,11 @@ static int g4_launch(Wino4WgradArgs& a, float* dW, bool bnf, hipStream_t s) {
   else wino4_wgrad_kernel<0><<<(unsigned)blocks, 256, lds, s>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd4_wgrad");
   const int n = a.Cin * a.Cout;
-  wino4_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(a.slab, dW, a.nrange, a.Cin, a.Cout);
+  if (a.nrange > 1) {
+    wino4_wgrad_reduce_kernel<<<(unsigned)cy_ceil_div(36ll * n, 256), 256, 0, s>>>(a.slab, a.nrange, 36ll * n);
+    CY_LAUNCH_CHECK("cy_conv3x3_winograd4_wgrad (reduce)");
+  }
+  wino4_wgrad_finish_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(a.slab, dW, a.Cin, a.Cout);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd4_wgrad (finish)");
   return 0;
 }
