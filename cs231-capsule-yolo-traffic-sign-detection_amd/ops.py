@@ -134,6 +134,8 @@ USE_CONV1 = True         # 3 -> {32, 64, 128} channels, 3x3, NCHW image (the bac
 USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short reductions; kept switchable)
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
+USE_WINOGRAD4_S2 = True  # 4x4 / stride-2 layers: forward on F(4x4,2x2) (winograd4_s2.hip: 1.44x fewer MFMAs than F(2x2,2x2)) from
+WINOGRAD4_S2_MIN_PIXELS = 1 << 16   # this many output pixels on (its 16 x 32-pixel blocks are the F(2x2,2x2) kernel's)
 USE_WINOGRAD4 = True     # ... forward and input gradient on F(4x4,3x3) (winograd4.hip: 1.78x fewer MFMAs) from WINOGRAD4_MIN_PIXELS output pixels on
 WINOGRAD4_MIN_PIXELS = 1 << 18   # 512 output pixels x 64 channels per block: below, its tile grid leaves most of the 256 CUs idle
 
@@ -214,10 +216,17 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
     if (USE_WINOGRAD and USE_WINOGRAD_S2 and not relu and k == 4 and stride == 2 and pad == 1 and not nchw
             and Cin % 8 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and x.is_contiguous()):
         st = _stream()
-        u = _empty((query('cy_wino2_packed_floats', Cin, Cout),), x)
-        call('cy_wino2_pack_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
         y = _empty((B, Ho, Wo, Cout), x)
         isc, ish, isl = in_affine if in_affine is not None else (None, None, 1.0)
+        if USE_WINOGRAD4_S2 and B * Ho * Wo >= WINOGRAD4_S2_MIN_PIXELS and query('cy_wino4s2_ok', B, Hi, Wi, Cin, Cout):
+            u = _empty((query('cy_wino4s2_packed_floats', Cin, Cout),), x)
+            call('cy_wino4s2_pack_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
+            with timer.range('conv_wino42_fwd/' + tag):
+                call('cy_conv4x4s2_winograd4', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
+                     float(isl), osl, B, Hi, Wi, Cin, Cout, st)
+            return y
+        u = _empty((query('cy_wino2_packed_floats', Cin, Cout),), x)
+        call('cy_wino2_pack_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
         with timer.range('conv_wino2_fwd/' + tag):
             call('cy_conv4x4s2_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), _ptr(isc), _ptr(ish),
                  float(isl), osl, B, Hi, Wi, Cin, Cout, st)

@@ -208,6 +208,15 @@ int cy_wino2_pack_weights(const float* W, float* U, int Cout, int Cin, void* str
 int cy_conv4x4s2_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats,
                           const float* in_scale, const float* in_shift, float in_slope, float out_slope,
                           int B, int H, int W, int Cin, int Cout, void* stream);
+/* The same forward through Winograd F(4x4,2x2) (25 multiplies per 4x4 outputs: 1.44x fewer MFMAs than F(2x2,2x2); fp32 error ~3e-6
+ * relative; same arguments and meaning as cy_conv4x4s2_winograd, own U layout).  Shapes: cy_wino4s2_ok (H, W even, Cin % 8 == 0, each
+ * image below 256 MB). */
+int cy_wino4s2_ok(int B, int H, int W, int Cin, int Cout);
+long long cy_wino4s2_packed_floats(int Cin, int N);
+int cy_wino4s2_pack_weights(const float* W, float* U, int Cout, int Cin, void* stream);
+int cy_conv4x4s2_winograd4(const float* X, const float* U, float* Y, const float* bias, double* stats,
+                           const float* in_scale, const float* in_shift, float in_slope, float out_slope,
+                           int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through F(2x2,2x2): dW[Cout][Cin][4][4] from X[B][H][W][Cin] and
  * dZ[B][H/2][W/2][Cout].  Cin % 32 == 0, Cout % 64 == 0, H and W even.  ws: cy_wino2_wgrad_ws_floats(B, Cin, Cout) floats
  * (per-image partial sums in the Winograd domain, reduced in a fixed order: deterministic). */

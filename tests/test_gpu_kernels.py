@@ -246,10 +246,13 @@ def test_conv3x3_winograd_wgrad_matches_direct_and_fp64(case):
 
 @pytest.mark.parametrize('case', [(2, 64, 32, 64), (1, 8, 10, 64), (3, 16, 70, 40), (2, 256, 36, 128), (1, 24, 6, 10),
                                   (2, 8, 128, 64)])
-def test_conv4x4s2_winograd_matches_direct_and_fp64(case):
+@pytest.mark.parametrize('f42', [False, True])
+def test_conv4x4s2_winograd_matches_direct_and_fp64(case, f42, monkeypatch):
     """Fused Winograd F(2x2,2x2) forward of the 4x4 / stride 2 / pad 1 layers (bias, BatchNorm statistics, image
     borders, partial blocks, padded channels) against torch fp64 and, switched off, the direct implicit GEMM."""
     from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_S2', f42)       # F(4x4,2x2) (winograd4_s2.hip) forced on / off
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
     B, Cin, H, Cout = case
     x = rnd((B, Cin, H, H), 81)
     w = rnd((Cout, Cin, 4, 4), 82, (1.0 / (Cin * 16)) ** 0.5)
@@ -265,7 +268,7 @@ def test_conv4x4s2_winograd_matches_direct_and_fp64(case):
     finally:
         ops.timer.enabled = False
     torch.cuda.synchronize()
-    assert 'conv_wino2_fwd/c3' in ops.timer.summary()
+    assert ('conv_wino42_fwd/c3' if f42 else 'conv_wino2_fwd/c3') in ops.timer.summary()
     stats = stats.sum(0)
     close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
     close(stats[:, 0], zr.sum(dim=(0, 2, 3)), 1e-4, 1e-4)
@@ -312,11 +315,14 @@ def test_conv4x4s2_winograd_wgrad_matches_direct_and_fp64(case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 32, 64), (3, 32, 70, 128), (1, 256, 12, 64)])
-def test_conv4x4s2_winograd_fused_input_affine(case):
+@pytest.mark.parametrize('f42', [False, True])
+def test_conv4x4s2_winograd_fused_input_affine(case, f42, monkeypatch):
     """The 4x4 / stride-2 Winograd forward and weight gradient with the producer's BatchNorm + LeakyReLU applied on
     their loads (X = raw conv output of the previous layer) against torch fp64 on the explicitly activated input;
-    the zero padding must stay zero (not lrelu(shift))."""
+    the zero padding must stay zero (not lrelu(shift)).  f42: the forward on F(4x4,2x2)."""
     from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_S2', f42)
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
     B, Cin, H, Cout = case
     zprev = rnd((B, Cin, H, H), 101)
     sc, sh = rnd((Cin,), 102, 0.5) + 1.0, rnd((Cin,), 103, 0.5)
@@ -487,6 +493,8 @@ def test_first_block_on_smooth_bright_images_with_zero_sum_filters(kind, edge, o
     (128, 256, 3, 1, 1, 20, 2, False, True),      # fused Winograd F(4x4,3x3) forward, LeakyReLU epilogue
     (64, 72, 3, 1, 1, 37, 3, False, True),        # ... odd size, padded channels, partial tile blocks
     (256, 64, 4, 2, 1, 24, 2, False, False),      # fused Winograd F(2x2,2x2) (4x4 / stride 2)
+    (256, 64, 4, 2, 1, 24, 2, False, 42),         # fused Winograd F(4x4,2x2) forward, LeakyReLU epilogue
+    (64, 72, 4, 2, 1, 38, 3, False, 42),          # ... odd map, padded channels
     (64, 128, 4, 2, 1, 10, 3, False, False),
     (128, 64, 1, 1, 0, 9, 2, False, False),       # implicit GEMM (DarkNet's 1x1 layers), act = 2
     (16, 40, 3, 1, 1, 11, 2, False, False),       # implicit GEMM, padded channels
@@ -496,8 +504,10 @@ def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw
     """Eval-mode conv -> BatchNorm -> LeakyReLU(0.1) as ONE launch (cy_bn_fold_eval + the conv kernel's LeakyReLU epilogue),
     every forward kernel class, against torch fp64 modules in eval mode."""
     from capsyolo_amd import _lib, models, ops
-    monkeypatch.setattr(ops, 'USE_WINOGRAD4', f4)
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4', f4 is True)
     monkeypatch.setattr(ops, 'WINOGRAD4_MIN_PIXELS', 0)
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_S2', f4 == 42)
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
     torch.manual_seed(11)
     conv = torch.nn.Conv2d(cin, cout, k, stride, pad).double()
     bn = torch.nn.BatchNorm2d(cout).double()
@@ -526,7 +536,7 @@ def test_eval_block_batchnorm_folded_into_the_conv(cin, cout, k, stride, pad, hw
             _lib.TRACE = None
     assert 'cy_affine_act' not in calls, calls
     assert ('cy_bn_fold_eval' in calls) != nchw
-    assert ('cy_conv3x3_winograd4' in calls) == f4
+    assert ('cy_conv3x3_winograd4' in calls) == (f4 is True) and ('cy_conv4x4s2_winograd4' in calls) == (f4 == 42)
     close(yh.permute(0, 3, 1, 2), yr, 1e-4, 2e-5)
 
 

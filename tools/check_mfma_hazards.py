@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'cs231-capsule-yolo-traffic-sign-detection_amd', 'csrc')
 FLAGS = {'routing_rows.hip': ['-fno-slp-vectorize'], 'routing_caps.hip': ['-fno-slp-vectorize']}
 
-ASM_MFMA_SOURCES = ['winograd.hip', 'winograd4.hip', 'winograd4_wgrad.hip', 'winograd_s2.hip', 'conv_bf16.hip', 'conv.hip']    # checked by default (and by build())
+ASM_MFMA_SOURCES = ['winograd.hip', 'winograd4.hip', 'winograd4_wgrad.hip', 'winograd4_s2.hip', 'winograd_s2.hip', 'conv_bf16.hip', 'conv.hip']    # checked by default (and by build())
 
 # passes of the MFMA forms these sources use (MI355X_MICROARCH.md, matrix-core cycle table: cycles per SIMD / 4)
 PASSES = [(r'v_mfma_f32_32x32x2_?f32', 16), (r'v_mfma_f32_16x16x4_?f32', 8), (r'v_mfma_f32_32x32x16_bf16', 8),

@@ -20,7 +20,7 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, 'cs231-capsule-yolo-traffic-sign-detection_amd', 'csrc')
-SOURCES = ['winograd4.hip', 'winograd4_wgrad.hip']
+SOURCES = ['winograd4.hip', 'winograd4_wgrad.hip', 'winograd4_s2.hip']
 
 
 def regs(tok):
