@@ -77,6 +77,8 @@ _SIGS = {
     'cy_conv4x4s2_winograd': [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P],
     'cy_conv4x4s2_winograd4': [_P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _I, _I, _I, _P],
     'cy_wino4s2_pack_weights': [_P, _P, _I, _I, _P],
+    'cy_wino4s2_pack_dgrad_weights': [_P, _P, _I, _I, _P],
+    'cy_conv4x4s2_winograd4_dgrad': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
     'cy_conv4x4s2_winograd_wgrad': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_wino2_pack_dgrad_weights': [_P, _P, _I, _I, _P],
     'cy_conv4x4s2_winograd_dgrad': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P],
@@ -143,6 +145,8 @@ _RET = {
     'cy_wino2_packed_floats': (_L, [_I, _I]),
     'cy_wino4s2_packed_floats': (_L, [_I, _I]),
     'cy_wino4s2_ok': (_I, [_I, _I, _I, _I, _I]),
+    'cy_wino4s2_dgrad_ok': (_I, [_I, _I, _I, _I, _I]),
+    'cy_wino4s2_dgrad_packed_floats': (_L, [_I, _I]),
     'cy_wino2_dgrad_packed_floats': (_L, [_I, _I]),
     'cy_wino2_wgrad_ws_floats': (_L, [_I, _I, _I]),
     'cy_wino_wgrad_ws_floats': (_L, [_I, _I, _I]),

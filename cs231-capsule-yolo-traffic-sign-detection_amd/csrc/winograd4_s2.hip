@@ -42,6 +42,13 @@ struct Wino4S2Args {
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
   int ntiles;
   float out_slope;
+  // input-gradient mode (MODE 1): X = dY [B][H][W][Cin] (H, W, Cin = the layer's output map and channels), Y = dX [B][Hx][Wx][Cx] of the
+  // layer, scattered from the (Ho x Wo = Hx/2+1 x Wx/2+1) grid of the space-to-depth view; Cout = Np = 4 Cx; optional BatchNorm-
+  // backward sums of the producer block (cy_conv_gemm_t.bn_*): then d = dX * lrelu'(z * scale + shift) is what is stored
+  int Hx, Wx, Cx;
+  const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
+  double* bn_red; float bn_slope;
+  int stagger;                                  // input gradient: start delay per block group, in units of s_sleep(127) (see h4_run)
 };
 
 __device__ __forceinline__ void h4_mfma(f32x4& c, float a, float b) {
@@ -115,7 +122,11 @@ constexpr int h4_younger_b(int role, int q) { return (H4_NP - 1 - q) + h4_vm_bet
 // ... and than the load of patch item k when RG(k) stores it one chunk later: 4 - k patch loads, 13 B loads, k patch loads
 constexpr int h4_younger_r(int k) { return (H4_NQ - 1 - k) + H4_NP + k; }
 
-template <int EPI, bool AFFINE, int ROLE>
+// MODE 0: forward.  MODE 1 (2: with the producer's BatchNorm-backward sums): input gradient: dX'(Y, X, q) = sum_{a',b'} D(Y + a', X + b', co) h(q, co, a', b') with D(Y, X) = dY(Y - 1, X - 1)
+// (zero outside) and h(q, co, a', b') = g'(co, q, 1 - a', 1 - b'): the same 2x2 "valid" convolution over the plain NHWC tensor dY shifted by one
+// pixel, K = Cout of the layer (chunks of 8 output channels, one class), N = 4 Cin; the drain scatters (Y, X, q = (py, px, c)) to
+// dX(2Y - 1 + py, 2X - 1 + px, c).
+template <int EPI, bool AFFINE, int ROLE, int MODE>
 __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   float* Vs = smem;                             // [2][H4_V_BUF]
   float* Rs = smem + 2 * H4_V_BUF;              // [2][H4_RAW_BUF]
@@ -128,12 +139,18 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
     for (int i = t; i < a.Cin; i += 256) { Aff[i] = a.in_scale[i]; Aff[a.Cin + i] = a.in_shift[i]; }
     __syncthreads();
   }
+  if constexpr (MODE != 0) {
+    // Every block does the same work per tile (a chunk loop of Cout / 8 chunks, then 128 KB of stores and, with the sums, 128 KB of z
+    // reads), so all 256 CUs would drain at the same moment: HBM saturated in the drains and idle in the chunk loops.  Four groups
+    // of blocks (interleaved within each XCD) start a fraction of a tile period apart and keep that phase.
+    for (int i = ((blockIdx.x >> 3) & 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
+  }
   unsigned vid = blockIdx.x;
   if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
   const int nblk = a.Np / 64;
   const int ntile_mine = (a.ntiles - (int)vid + (int)gridDim.x - 1) / (int)gridDim.x;
   const int cpp = a.Cin / 8;                    // chunks per (py, px) class
-  const int nchunk = 4 * cpp;
+  const int nchunk = MODE == 0 ? 4 * cpp : cpp;
   struct TilePos { int nb, b, Y0, X0; };
   auto tile_pos = [&](int k) {
     const int id = (int)vid + k * (int)gridDim.x;
@@ -159,16 +176,23 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   auto set_raw_tile = [&](int k) {
     const TilePos p = tile_pos(k);
     const unsigned long long xb = (unsigned long long)(uintptr_t)((const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin) - xshift);
-    xdesc = i32x4h_{(int)(unsigned)xb, (int)(unsigned)((xb >> 32) & 0xffffu), img_bytes + xshift, 0x00020000};
+    // (readfirstlane: an "s" asm operand must be provably uniform, and the image index comes out of vector-float divisions)
+    xdesc = i32x4h_{__builtin_amdgcn_readfirstlane((int)(unsigned)xb), __builtin_amdgcn_readfirstlane((int)(unsigned)((xb >> 32) & 0xffffu)),
+                    __builtin_amdgcn_readfirstlane(img_bytes + xshift), 0x00020000};
 #pragma unroll
     for (int q = 0; q < H4_NQ; ++q) {
       const int pix = pix0 + 128 * ((q < H4_NQ - 1 || rlast_ok) ? q : q - 1);
       const int pr = pix / H4_PC, pc = pix - pr * H4_PC;
       const int Yg = p.Y0 + pr, Xg = p.X0 + pc;      // grid point of X': input rows 2 Yg - 1 + py, columns 2 Xg - 1 + px
-      gvoff[q] = (unsigned)(((2 * Yg * a.W + 2 * Xg) * a.Cin + kq_of_thread * 4) * 4);
-      // py = 0 needs Yg >= 1 (and 2 Yg - 1 < H), py = 1 needs 2 Yg < H; the same for the columns; grid points behind Ho / Wo: never valid
-      hfl[q] = ((Yg < 1 || 2 * Yg - 1 >= a.H) ? 1u << 28 : 0u) | ((2 * Yg >= a.H) ? 1u << 29 : 0u) |
-               ((Xg < 1 || 2 * Xg - 1 >= a.W) ? 1u << 30 : 0u) | ((2 * Xg >= a.W) ? 1u << 31 : 0u);
+      if constexpr (MODE == 0) {
+        gvoff[q] = (unsigned)(((2 * Yg * a.W + 2 * Xg) * a.Cin + kq_of_thread * 4) * 4);
+        // py = 0 needs Yg >= 1 (and 2 Yg - 1 < H), py = 1 needs 2 Yg < H; the same for the columns; grid points behind Ho / Wo: never valid
+        hfl[q] = ((Yg < 1 || 2 * Yg - 1 >= a.H) ? 1u << 28 : 0u) | ((2 * Yg >= a.H) ? 1u << 29 : 0u) |
+                 ((Xg < 1 || 2 * Xg - 1 >= a.W) ? 1u << 30 : 0u) | ((2 * Xg >= a.W) ? 1u << 31 : 0u);
+      } else {                                  // D(Yg, Xg) = dY(Yg - 1, Xg - 1): the shifted base takes the -1s
+        gvoff[q] = (unsigned)(((Yg * a.W + Xg) * a.Cin + kq_of_thread * 4) * 4);
+        hfl[q] = ((Yg < 1 || Yg > a.H) ? 1u << 28 : 0u) | ((Xg < 1 || Xg > a.W) ? 1u << 30 : 0u);
+      }
     }
   };
   auto advance = [&](int& k, int& c) {
@@ -180,6 +204,12 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   unsigned rsoff = 0, rbt = 0;                  // uniform: scalar offset and border mask of the cursor's chunk
   int rc0 = 0;                                  // first channel of the cursor's chunk
   auto set_raw_chunk = [&]() {
+    if constexpr (MODE != 0) {
+      rc0 = cr * 8;
+      rsoff = (unsigned)__builtin_amdgcn_readfirstlane(cr * 32);
+      rbt = (1u << 28) | (1u << 30);
+      return;
+    }
     const int cls = cr / cpp, cc = cr - cls * cpp;
     rc0 = cc * 8;
     // (readfirstlane: the quotient cr / cpp comes out of a vector-float sequence, and an "s" asm operand must be provably uniform)
@@ -332,6 +362,28 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   fa[0] = *(const f32x4*)(Vs + fragA);
   fa[1] = *(const f32x4*)(Vs + fragA + 256);
   int c_next = 0;
+  const f32x2 kd2 = {2.f, 2.f}, kd4 = {4.f, 4.f}, kd8 = {8.f, 8.f};
+  // input-gradient mode: the producer's BatchNorm-backward sums stay in the lanes' registers over all tiles of the block's channel
+  // block (lane = 4 channels of one of 16 pixels) and go out through wave shuffles and double atomics when it changes / at the end
+  f32x4 b1 = {0.f, 0.f, 0.f, 0.f}, b2 = b1;
+  int bn_nb = -1;
+  auto flush_bn = [&](int nbx) {
+    const int q0x = nbx * 64, cb0x = q0x - (q0x / a.Cx) * a.Cx;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int msk = 4; msk < 64; msk <<= 1) { b1[k] += __shfl_xor(b1[k], msk, 64); b2[k] += __shfl_xor(b2[k], msk, 64); }
+    if (lane < 4) {
+      double* rd = a.bn_red + (size_t)(blockIdx.x % CY_STATS_COPIES) * a.Cx * 2;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int ch = cb0x + wave * 16 + lane * 4 + k;
+        atomicAdd(rd + 2 * ch, (double)b1[k]);
+        atomicAdd(rd + 2 * ch + 1, (double)b2[k]);
+      }
+    }
+    b1 = f32x4{0.f, 0.f, 0.f, 0.f}; b2 = b1;
+  };
   for (int km = 0; km < ntile_mine; ++km) {
     f32x4 acc[25][2];
 #pragma unroll
@@ -382,6 +434,105 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
       if (advance(ku, cu)) {}
       up_nxt = u_ptr(ku, cu);
     }
+    if constexpr (MODE != 0) {
+      // ======== input gradient: the same A^T M A; grid point (Yg, Xg) of q block nb = one (py, px) class and 64 channels of it
+      const TilePos tp = tile_pos(km);
+      float* ow = Os + wave * (2 * H4_OSTEP);
+      const int g_ = lane >> 4, co16 = lane & 15;
+      const int q0 = tp.nb * 64, ph = q0 / a.Cx, cb0 = q0 - ph * a.Cx, py = ph >> 1, px = ph & 1;
+      const int pxl = lane >> 2, cq = lane & 3, ly = pxl >> 2, lx = pxl & 3;
+      const int cch = cb0 + wave * 16 + cq * 4;                 // first of this lane's 4 channels in the read-back
+      constexpr bool bnb = MODE == 2;        // (a template parameter: the z loads and their waits are then on the same paths)
+      if (bnb && bn_nb >= 0 && bn_nb != tp.nb) flush_bn(bn_nb);   // (uniform, rare) another channel block: hand over the sums so far
+      bn_nb = tp.nb;
+      f32x4 bsc = {0.f, 0.f, 0.f, 0.f}, bsh = bsc, bnm = bsc, bis = bsc;
+      if constexpr (bnb) {                                // (tracked loads: they are waited for right here, before the chunk loop can see them pending)
+        bsc = *(const f32x4*)(a.bn_scale + cch); bsh = *(const f32x4*)(a.bn_shift + cch);
+        bis = *(const f32x4*)(a.bn_invstd + cch);
+        bnm = -*(const f32x4*)(a.bn_mean + cch) * bis;
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(bsc), "+v"(bsh), "+v"(bis), "+v"(bnm));
+      }
+      const int rowstride = 2 * a.Wx * a.Cx, colstride = 2 * a.Cx;          // floats per grid row / column
+      const unsigned lane_off = (unsigned)(ly * rowstride + lx * colstride + cq * 4);
+      const long long tile_off = ((long long)tp.b * a.Hx + (2 * tp.Y0 - 1 + py)) * a.Wx * a.Cx + (long long)(2 * tp.X0 - 1 + px) * a.Cx + cb0 + wave * 16;
+      float* ytile = a.Y + tile_off;
+      const float* ztile = a.bn_z + tile_off;
+      // valid grid rows / columns: iy = 2 Yg - 1 + py in [0, Hx) <=> 1 - py <= Yg < Ho - py
+      const bool full = tp.Y0 >= 1 - py && tp.Y0 + 16 <= a.Ho - py && tp.X0 >= 1 - px && tp.X0 + 32 <= a.Wo - px;
+#pragma unroll
+      for (int sp = 0; sp < 4; ++sp) {
+        const int h = sp >> 1, r0 = 2 * (sp & 1);
+        f32x4 zq[2][4];
+        if constexpr (bnb) {                              // the tile pair's z values: requested before the transform runs
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int Tj = 16 * h + 4 * j + r0 + rr;
+              const int Yg = tp.Y0 + 4 * (Tj >> 3) + ly, Xg = tp.X0 + 4 * (Tj & 7) + lx;
+              const bool ok = full || (Yg >= 1 - py && Yg < a.Ho - py && Xg >= 1 - px && Xg < a.Wo - px);
+              // (no branch around the load: lanes outside the image read the tensor's first values and never use them)
+              const float* zp = ok ? ztile + (4 * (Tj >> 3)) * rowstride + (4 * (Tj & 7)) * colstride + lane_off : a.bn_z;
+              asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(zq[rr][j]) : "v"(zp));
+            }
+        }
+        f32x2 S[5][4];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+          f32x2 m[5];
+#pragma unroll
+          for (int j = 0; j < 5; ++j) { m[j][0] = h4_acc_elem(acc[5 * i + j][h][r0]); m[j][1] = h4_acc_elem(acc[5 * i + j][h][r0 + 1]); }
+          const f32x2 s12 = m[1] + m[2], d12 = m[1] - m[2];
+          S[i][0] = (m[0] + s12) + m[3];
+          S[i][1] = h4_fma(-kd2, m[3], d12);
+          S[i][2] = h4_fma(kd4, m[3], s12);
+          S[i][3] = h4_fma(-kd8, m[3], d12) + m[4];
+        }
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const f32x2 s12 = S[1][x] + S[2][x], d12 = S[1][x] - S[2][x];
+          f32x2 y[4];
+          y[0] = (S[0][x] + s12) + S[3][x];
+          y[1] = h4_fma(-kd2, S[3][x], d12);
+          y[2] = h4_fma(kd4, S[3][x], s12);
+          y[3] = h4_fma(-kd8, S[3][x], d12) + S[4][x];
+#pragma unroll
+          for (int yy = 0; yy < 4; ++yy) {
+            ow[g_ * H4_OG + (yy * 4 + x) * 16 + co16] = y[yy][0];
+            ow[H4_OSTEP + g_ * H4_OG + (yy * 4 + x) * 16 + co16] = y[yy][1];
+          }
+        }
+        if constexpr (bnb) {
+#pragma unroll
+          for (int rr = 0; rr < 2; ++rr) asm volatile("s_waitcnt vmcnt(0)" : "+v"(zq[rr][0]), "+v"(zq[rr][1]), "+v"(zq[rr][2]), "+v"(zq[rr][3]));
+        }
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int Tj = 16 * h + 4 * j + r0 + rr;
+            const f32x4 v = *(const f32x4*)(ow + rr * H4_OSTEP + j * H4_OG + pxl * 16 + cq * 4);
+            const int Yg = tp.Y0 + 4 * (Tj >> 3) + ly, Xg = tp.X0 + 4 * (Tj & 7) + lx;
+            const bool ok = full || (Yg >= 1 - py && Yg < a.Ho - py && Xg >= 1 - px && Xg < a.Wo - px);
+            float* yp = ytile + (4 * (Tj >> 3)) * rowstride + (4 * (Tj & 7)) * colstride + lane_off;
+            if (ok) {
+              f32x4 sv = v;
+              if constexpr (bnb) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                  const float z = zq[rr][j][k];
+                  const float yv = __builtin_fmaf(z, bsc[k], bsh[k]);
+                  const float d = yv > 0.f ? v[k] : v[k] * a.bn_slope;
+                  sv[k] = d;
+                  b1[k] += d;
+                  b2[k] = __builtin_fmaf(d, __builtin_fmaf(z, bis[k], bnm[k]), b2[k]);
+                }
+              }
+              __builtin_nontemporal_store(sv, (f32x4*)yp);
+            }
+          }
+      }
+    } else {
     // ======== tile km is complete: lane-local output transform (25 -> 16 per tile and channel), two accumulator rows at a time
     const TilePos tp = tile_pos(km);
     float* ow = Os + wave * (2 * H4_OSTEP);
@@ -398,7 +549,7 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
     const int cbase = tp.nb * 64 + wave * 16 + cq * 4;
     const unsigned lane_off = (unsigned)(((pxl >> 2) * a.Wo + (pxl & 3)) * a.Cout + cq * 4);
     float* ybase = a.Y + (((long long)tp.b * a.Ho + tp.Y0) * a.Wo + tp.X0) * a.Cout + tp.nb * 64 + wave * 16;
-    const f32x2 kd2 = {2.f, 2.f}, kd4 = {4.f, 4.f}, kd8 = {8.f, 8.f}, bv2 = {bv, bv};
+    const f32x2 bv2 = {bv, bv};
     f32x2 ssum2 = {0.f, 0.f}, ssq2 = {0.f, 0.f};
     float esum = 0.f, esq = 0.f;                // statistics of blocks that reach over the map's edge
 #pragma unroll
@@ -472,7 +623,9 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
         atomicAdd(st + 2 * co + 1, (double)ssq);
       }
     }
+    }
   }
+  if constexpr (MODE == 2) { if (bn_nb >= 0) flush_bn(bn_nb); }
   // the prefetch behind the block's last chunk is still in flight: its registers must not be reused before it has landed
 #pragma unroll
   for (int q = 0; q < H4_NQ; ++q) h4_vmwait<0>(graw[q]);
@@ -480,11 +633,43 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   for (int q = 0; q < H4_NP; ++q) h4_vmwait<0>(bq[q]);
 }
 
-template <int EPI, bool AFFINE>
+template <int EPI, bool AFFINE, int MODE = 0>
 __global__ __launch_bounds__(256, 1) void wino4s2_conv_kernel(Wino4S2Args a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  if (threadIdx.x < 128) h4_run<EPI, AFFINE, 0>(a, smem);
-  else h4_run<EPI, AFFINE, 1>(a, smem);
+  if (threadIdx.x < 128) h4_run<EPI, AFFINE, 0, MODE>(a, smem);
+  else h4_run<EPI, AFFINE, 1, MODE>(a, smem);
+}
+
+// input-gradient operand: U[nb (q block)][chunk (co / 8)][wave][pair][lane][e]: q = 64 nb + 16 wave + (l & 15) = (py, px, c),
+// co = 8 chunk + 2 (l >> 4) + s; value (G h G^T)[i][j], h[a'][b'] = W[co][c][2 (1 - a') + py][2 (1 - b') + px]
+__global__ void wino4s2_pack_dgrad_kernel(const float* __restrict__ W, float* __restrict__ U, int Cout, int Cin, long long total) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one (co, q) per thread
+  if (idx >= total) return;
+  const int Np = 4 * Cin;
+  const int q = (int)(idx % Np), co = (int)(idx / Np);
+  const int ph = q / Cin, c = q - ph * Cin, py = ph >> 1, px = ph & 1;
+  float g[2][2];
+#pragma unroll
+  for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) g[aa][bb] = W[(((long long)co * Cin + c) * 4 + (2 * (1 - aa) + py)) * 4 + (2 * (1 - bb) + px)];
+  const float Gm[5][2] = {{0.5f, 0.f}, {1.f / 6, 1.f / 6}, {0.5f, -0.5f}, {1.f / 6, -1.f / 3}, {0.f, 1.f}};
+  const int nb = q >> 6, wv = (q >> 4) & 3, c16 = q & 15;
+  const int nchunk = Cout / 8, cc = co >> 3, kgp = (co >> 1) & 3, s = co & 1;
+  float* out = U + ((((long long)nb * nchunk + cc) * 4 + wv) * H4_NP) * 256 + (kgp * 16 + c16) * 4;
+#pragma unroll
+  for (int i = 0; i < 5; ++i)
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int pos = 5 * i + j;
+      float u = 0.f;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) u += Gm[i][p] * g[p][r] * Gm[j][r];
+      out[(pos >> 1) * 256 + 2 * (pos & 1) + s] = u;
+    }
+  out[12 * 256 + 2 + s] = 0.f;
 }
 
 // U[nb][f = cls * Cin/8 + cc][wave][pair q][lane l][e]: pos = 2 q + (e >> 1) = 5 i + j, s = e & 1, co = 64 nb + 16 wave + (l & 15),
@@ -578,5 +763,59 @@ extern "C" int cy_conv4x4s2_winograd4(const float* X, const float* U, float* Y, 
   else H4_LAUNCH(0, false)
 #undef H4_LAUNCH
   CY_LAUNCH_CHECK("cy_conv4x4s2_winograd4");
+  return 0;
+}
+
+extern "C" int cy_wino4s2_dgrad_ok(int B, int H, int W, int Cin, int Cout) {     // H, W, Cin, Cout of the LAYER (dX is [B][H][W][Cin])
+  return B > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 1) == 0 && Cin % 64 == 0 && Cout % 8 == 0 && Cout >= 8 &&
+         (long long)(H / 2) * (W / 2) * Cout * 4 + (long long)(W / 2 + 1) * Cout * 4 < (1ll << 28) && (long long)H * W * Cin < (1ll << 29);
+}
+
+extern "C" long long cy_wino4s2_dgrad_packed_floats(int Cin, int Cout) { return (long long)Cout * 26 * 4 * Cin; }
+
+extern "C" int cy_wino4s2_pack_dgrad_weights(const float* W, float* U, int Cout, int Cin, void* stream) {
+  CY_REQUIRE(W && U && Cout > 0 && Cin > 0 && Cout % 8 == 0 && Cin % 16 == 0, "cy_wino4s2_pack_dgrad_weights: bad arguments");
+  const long long total = 4ll * Cin * Cout;
+  wino4s2_pack_dgrad_kernel<<<(unsigned)cy_ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(W, U, Cout, Cin, total);
+  CY_LAUNCH_CHECK("cy_wino4s2_pack_dgrad_weights");
+  return 0;
+}
+
+extern "C" int cy_conv4x4s2_winograd4_dgrad(const float* dZ, const float* U, float* dX, const float* bn_z, const float* bn_scale,
+                                            const float* bn_shift, const float* bn_mean, const float* bn_invstd, float bn_slope,
+                                            double* bn_red, int B, int H, int W, int Cin, int Cout, void* stream) {
+  CY_REQUIRE(dZ && U && dX, "cy_conv4x4s2_winograd4_dgrad: bad arguments");
+  CY_REQUIRE(cy_wino4s2_dgrad_ok(B, H, W, Cin, Cout), "cy_conv4x4s2_winograd4_dgrad: shape B=%d H=%d W=%d Cin=%d Cout=%d not supported", B, H, W, Cin, Cout);
+  CY_REQUIRE((((uintptr_t)dZ | (uintptr_t)U | (uintptr_t)dX | (uintptr_t)bn_z) & 15) == 0, "cy_conv4x4s2_winograd4_dgrad: operands must be 16-byte aligned");
+  CY_REQUIRE(bn_red == nullptr || (bn_z && bn_scale && bn_shift && bn_mean && bn_invstd), "cy_conv4x4s2_winograd4_dgrad: bn_red needs bn_z / scale / shift / mean / invstd");
+  Wino4S2Args a{};
+  a.X = dZ; a.U = U; a.Y = dX; a.in_slope = 1.f; a.out_slope = 1.f;
+  a.B = B; a.H = H / 2; a.W = W / 2; a.Cin = Cout;          // the kernel's "input" is dY [B][H/2][W/2][Cout]
+  a.Cout = 4 * Cin; a.Np = 4 * Cin;
+  a.Ho = H / 2 + 1; a.Wo = W / 2 + 1;                       // grid of the space-to-depth view
+  a.tbh = (a.Ho + 15) / 16; a.tbw = (a.Wo + 31) / 32;
+  a.Hx = H; a.Wx = W; a.Cx = Cin;
+  a.bn_z = bn_z; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
+  a.bn_red = bn_red; a.bn_slope = bn_slope;
+  a.stagger = 2;
+  if (const char* e = getenv("CY_H4_STAGGER")) a.stagger = atoi(e);     // (development knob)
+  const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / 64);
+  CY_REQUIRE(tiles < (1ll << 31), "cy_conv4x4s2_winograd4_dgrad: too many tiles");
+  a.ntiles = (int)tiles;
+  int dev = 0, ncu = 0;
+  hipError_t he = hipGetDevice(&dev);
+  if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+  if (he != hipSuccess || ncu <= 0) return cy_set_error((int)he, "cy_conv4x4s2_winograd4_dgrad: cannot query the CU count: %s", hipGetErrorString(he));
+  long long blocks = tiles < ncu ? tiles : ncu;
+  // a grid that is a multiple of the number of channel blocks keeps every block on ONE channel block (its BatchNorm sums leave once)
+  const int nblk = a.Np / 64;
+  if (blocks > nblk) blocks -= blocks % nblk;
+  const size_t lds = (size_t)(2 * H4_V_BUF + 2 * H4_RAW_BUF + 8 * H4_OSTEP) * 4;
+  int rc = cy_allow_lds(wino4s2_conv_kernel<0, false, 1>, lds);
+  if (!rc) rc = cy_allow_lds(wino4s2_conv_kernel<0, false, 2>, lds);
+  if (rc) return rc;
+  if (bn_red != nullptr) wino4s2_conv_kernel<0, false, 2><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else wino4s2_conv_kernel<0, false, 1><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  CY_LAUNCH_CHECK("cy_conv4x4s2_winograd4_dgrad");
   return 0;
 }

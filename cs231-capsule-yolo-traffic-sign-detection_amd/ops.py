@@ -135,6 +135,7 @@ USE_WINOGRAD_S2_DGRAD = True   # ... and their input gradient (K = Cout: short r
 USE_WINOGRAD_S2 = True   # 4x4 / stride 2 / pad 1 layers: fused Winograd F(2x2,2x2) forward on the space-to-depth view
 USE_WINOGRAD = True      # 3x3 / stride 1 / pad 1 layers with Cin % 8 == 0 take the fused Winograd F(2x2,3x3) kernel
 USE_WINOGRAD4_S2 = True  # 4x4 / stride-2 layers: forward on F(4x4,2x2) (winograd4_s2.hip: 1.44x fewer MFMAs than F(2x2,2x2)) from
+USE_WINOGRAD4_S2_DGRAD = True      # ... and their input gradient (the same kernel over dY shifted by one pixel, scattered to the four classes)
 WINOGRAD4_S2_MIN_PIXELS = 1 << 16   # this many output pixels on (its 16 x 32-pixel blocks are the F(2x2,2x2) kernel's)
 USE_WINOGRAD4 = True     # ... forward and input gradient on F(4x4,3x3) (winograd4.hip: 1.78x fewer MFMAs) from WINOGRAD4_MIN_PIXELS output pixels on
 WINOGRAD4_MIN_PIXELS = 1 << 18   # 512 output pixels x 64 channels per block: below, its tile grid leaves most of the 256 CUs idle
@@ -294,15 +295,23 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv', bn_fuse=None, i
     dx = _empty((B, Hi, Wi, Cin), dz)
     if (USE_WINOGRAD and USE_WINOGRAD_S2 and USE_WINOGRAD_S2_DGRAD and k == 4 and stride == 2 and pad == 1 and Cin % 64 == 0
             and Cout % 8 == 0 and Hi % 2 == 0 and Wi % 2 == 0 and dz.is_contiguous()):
-        u = _empty((query('cy_wino2_dgrad_packed_floats', Cin, Cout),), dz)
-        call('cy_wino2_pack_dgrad_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
         bz = bsc = bsh = bmu = bis = bred = None
         bsl = 0.0
         if bn_fuse is not None:
             bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
-        with timer.range('conv_wino2_dgrad/' + tag):
-            call('cy_conv4x4s2_winograd_dgrad', _ptr(dz), _ptr(u), _ptr(dx), _ptr(bz), _ptr(bsc), _ptr(bsh), _ptr(bmu),
-                 _ptr(bis), float(bsl), _ptr(bred), B, Hi, Wi, Cin, Cout, st)
+        if (USE_WINOGRAD4_S2 and USE_WINOGRAD4_S2_DGRAD and B * Ho * Wo >= WINOGRAD4_S2_MIN_PIXELS
+                and query('cy_wino4s2_dgrad_ok', B, Hi, Wi, Cin, Cout)):
+            u = _empty((query('cy_wino4s2_dgrad_packed_floats', Cin, Cout),), dz)
+            call('cy_wino4s2_pack_dgrad_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
+            with timer.range('conv_wino42_dgrad/' + tag):
+                call('cy_conv4x4s2_winograd4_dgrad', _ptr(dz), _ptr(u), _ptr(dx), _ptr(bz), _ptr(bsc), _ptr(bsh), _ptr(bmu),
+                     _ptr(bis), float(bsl), _ptr(bred), B, Hi, Wi, Cin, Cout, st)
+        else:
+            u = _empty((query('cy_wino2_dgrad_packed_floats', Cin, Cout),), dz)
+            call('cy_wino2_pack_dgrad_weights', _ptr(weight), _ptr(u), Cout, Cin, st)
+            with timer.range('conv_wino2_dgrad/' + tag):
+                call('cy_conv4x4s2_winograd_dgrad', _ptr(dz), _ptr(u), _ptr(dx), _ptr(bz), _ptr(bsc), _ptr(bsh), _ptr(bmu),
+                     _ptr(bis), float(bsl), _ptr(bred), B, Hi, Wi, Cin, Cout, st)
         if info is not None and bn_fuse is not None:
             info['premasked'] = True      # with the fused sums this kernel stores dx * lrelu'(y), not dx (capsyolo_hip.h)
         return dx

@@ -217,6 +217,16 @@ int cy_wino4s2_pack_weights(const float* W, float* U, int Cout, int Cin, void* s
 int cy_conv4x4s2_winograd4(const float* X, const float* U, float* Y, const float* bias, double* stats,
                            const float* in_scale, const float* in_shift, float in_slope, float out_slope,
                            int B, int H, int W, int Cin, int Cout, void* stream);
+/* Input gradient of the same layers through F(4x4,2x2): the arguments of cy_conv4x4s2_winograd_dgrad below (U =
+ * cy_wino4s2_pack_dgrad_weights(W[Cout][Cin][4][4]), cy_wino4s2_dgrad_packed_floats(Cin, Cout) floats; bn_* as there: with bn_red
+ * the kernel stores dX * lrelu'(z * scale + shift) and adds the producer BatchNorm's backward sums).  H, W, Cin, Cout are the
+ * LAYER's (dX is [B][H][W][Cin]); shapes: cy_wino4s2_dgrad_ok (H, W even, Cin % 64 == 0, Cout % 8 == 0). */
+int cy_wino4s2_dgrad_ok(int B, int H, int W, int Cin, int Cout);
+long long cy_wino4s2_dgrad_packed_floats(int Cin, int Cout);
+int cy_wino4s2_pack_dgrad_weights(const float* W, float* U, int Cout, int Cin, void* stream);
+int cy_conv4x4s2_winograd4_dgrad(const float* dZ, const float* U, float* dX, const float* bn_z, const float* bn_scale,
+                                 const float* bn_shift, const float* bn_mean, const float* bn_invstd, float bn_slope,
+                                 double* bn_red, int B, int H, int W, int Cin, int Cout, void* stream);
 /* Weight gradient of the same layers through F(2x2,2x2): dW[Cout][Cin][4][4] from X[B][H][W][Cin] and
  * dZ[B][H/2][W/2][Cout].  Cin % 32 == 0, Cout % 64 == 0, H and W even.  ws: cy_wino2_wgrad_ws_floats(B, Cin, Cout) floats
  * (per-image partial sums in the Winograd domain, reduced in a fixed order: deterministic). */

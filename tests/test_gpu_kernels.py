@@ -341,14 +341,17 @@ def test_conv4x4s2_winograd_fused_input_affine(case, f42, monkeypatch):
     close(dw, wd.grad, 2e-5, 2e-5 * wd.grad.abs().max().item())
 
 
-@pytest.mark.parametrize('case', [(2, 64, 16, 64, 4, 2, 1), (3, 32, 18, 128, 4, 2, 1), (2, 64, 9, 64, 1, 1, 0)])
-def test_conv_dgrad_epilogue_bn_backward_sums(case):
+@pytest.mark.parametrize('case', [(2, 64, 16, 64, 4, 2, 1), (3, 32, 18, 128, 4, 2, 1), (2, 64, 9, 64, 1, 1, 0),
+                                  (2, 128, 70, 40, 4, 2, 1, 42), (3, 64, 32, 64, 4, 2, 1, 42), (1, 256, 6, 16, 4, 2, 1, 42)])
+def test_conv_dgrad_epilogue_bn_backward_sums(case, monkeypatch):
     """The input-gradient kernel's optional BatchNorm-backward sums of the producer block (d = dx * lrelu'(y),
     sum d and sum d * xhat over the pixels it stores, all stride-parity classes together) against cy_bn_bwd_reduce
-    run on the same dx."""
+    run on the same dx.  Cases ending in 42: the F(4x4,2x2) kernel (winograd4_s2.hip), the others F(2x2,2x2) / the direct kernel."""
     from capsyolo_amd import ops
     from capsyolo_amd._lib import call
-    B, Cin, Hi, Cout, k, stride, pad = case
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_S2_DGRAD', len(case) == 8)
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
+    B, Cin, Hi, Cout, k, stride, pad = case[:7]
     Ho = (Hi + 2 * pad - k) // stride + 1
     dz = rnd((B, Ho, Ho, Cout), 111).to(dev())
     w = rnd((Cout, Cin, k, k), 112, 0.1).to(dev())
@@ -374,10 +377,13 @@ def test_conv_dgrad_epilogue_bn_backward_sums(case):
 
 
 @pytest.mark.parametrize('case', [(2, 64, 32, 64), (1, 64, 10, 8), (3, 128, 70, 40), (2, 256, 36, 64), (5, 64, 6, 16)])
-def test_conv4x4s2_winograd_dgrad_matches_direct_and_fp64(case):
-    """Winograd F(2x2,2x2) input gradient of the 4x4 / stride 2 / pad 1 layers (scatter through the space-to-depth view,
-    image borders, grid overhang) against torch fp64 and the direct per-parity-class kernel."""
+@pytest.mark.parametrize('f42', [False, True])
+def test_conv4x4s2_winograd_dgrad_matches_direct_and_fp64(case, f42, monkeypatch):
+    """Winograd F(2x2,2x2) / F(4x4,2x2) input gradient of the 4x4 / stride 2 / pad 1 layers (scatter through the space-to-depth
+    view, image borders, grid overhang) against torch fp64 and the direct per-parity-class kernel."""
     from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4_S2_DGRAD', f42)
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
     B, Cin, H, Cout = case
     x = rnd((B, Cin, H, H), 121)
     w = rnd((Cout, Cin, 4, 4), 122, (1.0 / (Cin * 16)) ** 0.5)
@@ -393,7 +399,7 @@ def test_conv4x4s2_winograd_dgrad_matches_direct_and_fp64(case):
     finally:
         ops.timer.enabled = False
     torch.cuda.synchronize()
-    assert 'conv_wino2_dgrad/dg' in ops.timer.summary()
+    assert ('conv_wino42_dgrad/dg' if f42 else 'conv_wino2_dgrad/dg') in ops.timer.summary()
     close(dx.permute(0, 3, 1, 2), xd.grad, 2e-5, 2e-5)
     try:
         ops.USE_WINOGRAD_S2_DGRAD = False

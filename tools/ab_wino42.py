@@ -42,3 +42,22 @@ for name, H, Cin, Cout in (('conv_3', 416, 256, 64), ('conv_4', 208, 64, 128), (
     z0, za0, t0, ta0 = res[False]; z1, za1, t1, ta1 = res[True]
     print('%s forward + stats: F(2x2,2x2) %.3f ms, F(4x4,2x2) %.3f ms (%.0f TFLOP/s direct-equivalent) | with the input affine %.3f -> %.3f ms | rel L2 diff %.2e / %.2e'
           % (name, t0, t1, fl / t1 / 1e9, ta0, ta1, float((z1 - z0).norm() / z0.norm()), float((za1 - za0).norm() / za0.norm())), flush=True)
+    # input gradient, plain and with the producer block's fused BatchNorm-backward sums
+    dz = torch.randn(B, H // 2, H // 2, Cout, device=dev)
+    zin = torch.randn(B, H, H, Cin, device=dev)
+    mu, isd = torch.randn(Cin, device=dev) * 0.1, torch.rand(Cin, device=dev) + 0.5
+    res = {}
+    for f42 in (False, True):
+        ops.USE_WINOGRAD4_S2_DGRAD = f42
+        red = torch.zeros(ops.STATS_COPIES, Cin, 2, dtype=torch.float64, device=dev)
+        dx = ops.conv_dgrad(dz, w, (B, H, H, Cin), 4, 2, 1)
+        dxb = ops.conv_dgrad(dz, w, (B, H, H, Cin), 4, 2, 1, 'c', (zin, sc, sh, mu, isd, 0.1, red), {})
+        redc = red.sum(0).clone()
+        t = med(lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), 4, 2, 1))
+        tb = med(lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), 4, 2, 1, 'c', (zin, sc, sh, mu, isd, 0.1, red), {}))
+        res[f42] = (dx, dxb, redc, t, tb)
+    d0, db0, r0, t0, tb0 = res[False]; d1, db1, r1, t1, tb1 = res[True]
+    print('%s input gradient: F(2x2,2x2) %.3f ms, F(4x4,2x2) %.3f ms (%.0f TFLOP/s direct-equivalent) | with the BatchNorm sums %.3f -> %.3f ms | rel L2 diff %.2e / %.2e, sums %.2e'
+          % (name, t0, t1, fl / t1 / 1e9, tb0, tb1, float((d1 - d0).norm() / d0.norm()), float((db1 - db0).norm() / db0.norm()),
+             float((r1 - r0).norm() / r0.norm())), flush=True)
+    del x, zin, dz, res

@@ -66,19 +66,31 @@ def check_kernel(name, body, max_steps=20000000):
         if m:
             labels[m.group(1)] = i
     instrs = [parse(l) for l in body]
-    errors, seen, nloads, nwaits = {}, set(), set(), set()
+    errors, seen, nloads, nwaits = {}, {}, set(), set()
     stack = [(0, ())]
     steps = 0
     while stack:
         pc, queue = stack.pop()
         queue = list(queue)
         while pc < len(body):
-            key = None
             if body[pc].startswith('.L'):
-                key = (pc, tuple(queue))
-                if key in seen:
+                # state at a label: the loads in flight, and how many stores stand behind each of them.  A state whose loads are
+                # the same and whose store counts are all >= those of a state already walked is covered by it (every wait retires
+                # at least as much there), so paths that differ only in which conditional stores ran do not multiply.
+                while queue and not queue[0][0]:
+                    queue.pop(0)              # stores older than every load in flight never matter again
+                loads = tuple(e for e in queue if e[0])
+                gaps, n = [], 0
+                for e in reversed(queue):
+                    if e[0]:
+                        gaps.append(n); n = 0
+                    else:
+                        n += 1
+                gaps = tuple(reversed(gaps))
+                known = seen.setdefault((pc, loads), [])
+                if any(all(k <= g for k, g in zip(kg, gaps)) for kg in known):
                     break
-                seen.add(key)
+                known.append(gaps)
             p = instrs[pc]
             pc += 1
             if p is None:
