@@ -48,7 +48,6 @@ struct Wino4S2Args {
   int Hx, Wx, Cx;
   const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
   double* bn_red; float bn_slope;
-  int stagger;                                  // input gradient: start delay per block group, in units of s_sleep(127) (see h4_run)
 };
 
 __device__ __forceinline__ void h4_mfma(f32x4& c, float a, float b) {
@@ -138,12 +137,6 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   if constexpr (AFFINE) {
     for (int i = t; i < a.Cin; i += 256) { Aff[i] = a.in_scale[i]; Aff[a.Cin + i] = a.in_shift[i]; }
     __syncthreads();
-  }
-  if constexpr (MODE != 0) {
-    // Every block does the same work per tile (a chunk loop of Cout / 8 chunks, then 128 KB of stores and, with the sums, 128 KB of z
-    // reads), so all 256 CUs would drain at the same moment: HBM saturated in the drains and idle in the chunk loops.  Four groups
-    // of blocks (interleaved within each XCD) start a fraction of a tile period apart and keep that phase.
-    for (int i = ((blockIdx.x >> 3) & 3) * a.stagger; i > 0; --i) __builtin_amdgcn_s_sleep(127);
   }
   unsigned vid = blockIdx.x;
   if ((gridDim.x & 7u) == 0) vid = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
@@ -797,8 +790,6 @@ extern "C" int cy_conv4x4s2_winograd4_dgrad(const float* dZ, const float* U, flo
   a.Hx = H; a.Wx = W; a.Cx = Cin;
   a.bn_z = bn_z; a.bn_scale = bn_scale; a.bn_shift = bn_shift; a.bn_mean = bn_mean; a.bn_invstd = bn_invstd;
   a.bn_red = bn_red; a.bn_slope = bn_slope;
-  a.stagger = 2;
-  if (const char* e = getenv("CY_H4_STAGGER")) a.stagger = atoi(e);     // (development knob)
   const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / 64);
   CY_REQUIRE(tiles < (1ll << 31), "cy_conv4x4s2_winograd4_dgrad: too many tiles");
   a.ntiles = (int)tiles;

@@ -241,6 +241,11 @@ def test_hand_counted_vmcnt_waits_cover_every_use_of_an_asm_loaded_register():
     weak = pro + ['\ts_waitcnt vmcnt(2)', '\tv_add_f32_e32 v10, v2, v2'] + loop
     assert chk.check_kernel('synthetic', ok)[2] == []
     assert len(chk.check_kernel('synthetic', weak)[2]) == 1
+    # conditional stores between a load and its wait: the path WITHOUT the store is the binding one (fewer younger operations)
+    cond = ['\tglobal_load_dwordx4 v[2:5], v0, s[0:1]', '\ts_cbranch_execz .LBB0_0', '\tglobal_store_dword v0, v1, s[0:1]', '.LBB0_0:']
+    assert chk.check_kernel('synthetic', cond + ['\ts_waitcnt vmcnt(0)', '\tv_add_f32_e32 v10, v2, v2'] + loop)[2] == []
+    assert len(chk.check_kernel('synthetic', cond + ['\ts_waitcnt vmcnt(1)', '\tv_add_f32_e32 v10, v2, v2'] + loop)[2]) == 1
     r = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_vmcnt.py')], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
-    assert 'check_vmcnt: ok' in r.stdout and r.stdout.count(', 0 uses') == 3
+    # every fused Winograd kernel with asm loads: 3 of winograd4.hip, 3 of winograd4_wgrad.hip, 7 of winograd4_s2.hip
+    assert 'check_vmcnt: ok' in r.stdout and r.stdout.count(', 0 uses') == r.stdout.count(' loads and ') == 13
