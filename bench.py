@@ -330,6 +330,7 @@ _KIND_PEAKS = {   # timer key prefix -> (issued / direct-convolution FLOPs, MFMA
     'conv_wino_wgrad': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino_wgrad_bn': (1 / 2.25, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino4_wgrad': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino4_wgrad_bn': (1 / 4.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_fwd': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino2_dgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS),
+    'conv_wino42_fwd': (25 / 64, PEAK_FP32_MATRIX_TFLOPS), 'conv_wino42_dgrad': (25 / 64, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wino2_wgrad': (9 / 16, PEAK_FP32_MATRIX_TFLOPS), 'conv_gemm_fwd': (1.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_wgrad': (1.0, PEAK_FP32_MATRIX_TFLOPS),
     'conv_bf16_fwd': (1.0, PEAK_BF16_MATRIX_TFLOPS), 'conv_bf16_wgrad': (1.0, PEAK_BF16_MATRIX_TFLOPS),

@@ -68,5 +68,18 @@ for (Cin, H, Cout, k, s) in ((128, 208, 256, 3, 1), (256, 208, 64, 4, 2), (64, 1
             rep(tag + 'fp32 F(4x4,3x3) fwd', lambda: ops.conv_forward(x, w, b, k, s, 1))
             rep(tag + 'fp32 F(4x4,3x3) dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), k, s, 1))
             ops.WINOGRAD4_MIN_PIXELS = old
+    if k == 4 and query('cy_wino4s2_ok', B, H, H, Cin, Cout) and query('cy_wino4s2_dgrad_ok', B, H, H, Cin, Cout):
+        old = ops.WINOGRAD4_S2_MIN_PIXELS
+        ops.WINOGRAD4_S2_MIN_PIXELS = 0
+        zz = torch.randn(B, H, H, Cin, device=dev)
+        sc, sh = torch.rand(Cin, device=dev) + 0.5, torch.randn(Cin, device=dev) * 0.3
+        mu, isd = torch.randn(Cin, device=dev) * 0.2, torch.rand(Cin, device=dev) * 0.3 + 0.5
+        red = torch.zeros(ops.STATS_COPIES, Cin, 2, dtype=torch.float64, device=dev)
+        rep(tag + 'fp32 F(4x4,2x2) fwd', lambda: ops.conv_forward(x, w, b, k, s, 1))
+        rep(tag + 'fp32 F(4x4,2x2) fwd, input affine', lambda: ops.conv_forward(x, w, None, k, s, 1, False, None, False, 'c', (sc, sh, 0.1)))
+        rep(tag + 'fp32 F(4x4,2x2) dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), k, s, 1))
+        # (the sums themselves are double atomics: the stored premasked gradient is what must repeat)
+        rep(tag + 'fp32 F(4x4,2x2) dgrad + BatchNorm sums (dx)', lambda: ops.conv_dgrad(dz, w, (B, H, H, Cin), k, s, 1, 'c', (zz, sc, sh, mu, isd, 0.1, red), {}))
+        ops.WINOGRAD4_S2_MIN_PIXELS = old
 print('check_determinism:', 'ok' if bad == 0 else 'FAILED')
 sys.exit(0 if bad == 0 else 1)

@@ -15,7 +15,7 @@ def load(path):
 
 
 m, l = load(sys.argv[1]), load(sys.argv[2])
-want = ('wino_conv_kernel', 'wino4_conv_kernel', 'wino4_wgrad_kernel', 'wino_wgrad_kernel', 'wino2_conv_kernel', 'wino2_wgrad_kernel', 'conv1_', 'caps1_')
+want = ('wino_conv_kernel', 'wino4_conv_kernel', 'wino4_wgrad_kernel', 'wino_wgrad_kernel', 'wino2_conv_kernel', 'wino4s2_conv_kernel', 'wino2_wgrad_kernel', 'conv1_', 'caps1_')
 out = {'method': 'rocprofv3 --pmc (two passes, --kernel-trace only) of tools/run_kernels.py all 32 1; last launch of each kernel; '
                  'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): the MFMA counter ticks per SIMD, four per CU '
                  '(cross-check: SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = the flops the kernel issues); '

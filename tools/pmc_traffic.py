@@ -34,6 +34,9 @@ pick = {
     'conv_wino_wgrad_bn/conv_2': ('wino_wgrad_kernel<2>', -1),    # (premasked gradient, as in the training step)
     'routing_fwd': ('caps1_fwd_kernel<5, true>', -1),
     'routing_bwd': ('caps1_bwd_kernel<5, true>', -1),
+    'conv_wino42_fwd/conv_3': ('wino4s2_conv_kernel<1, false, 0>', -1),      # (with the BatchNorm statistics)
+    'conv_wino42_dgrad/conv_3': ('wino4s2_conv_kernel<0, false, 2>', -1),    # (with conv_2's BatchNorm-backward sums: z read, premasked store)
+    'conv_wino42_dgrad_plain/conv_3': ('wino4s2_conv_kernel<0, false, 1>', -1),
     'conv_wino2_fwd/conv_3': ('wino2_conv_kernel<0, false>', -1),
     'conv_wino2_dgrad/conv_3': ('wino2_conv_kernel<1, false>', -1),
     'conv_wino2_wgrad/conv_3': ('wino2_wgrad_kernel<false>', -1),

@@ -66,6 +66,16 @@ if what in ('conv3', 'all'):
     fl = 2.0 * B * (H // 2) ** 2 * 64 * 4096
     timeit('conv3 fwd', lambda: ops.conv_forward(x, w, None, 4, 2, 1), fl)
     timeit('conv3 dgrad', lambda: ops.conv_dgrad(dz, w, (B, H, H, 256), 4, 2, 1), fl)
+    # as in the training step: with conv_2's BatchNorm-backward sums (z read, premasked gradient stored), and the forward with
+    # its own BatchNorm statistics
+    z3 = torch.randn(B, H, H, 256, device=dev)
+    sc3, sh3 = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+    mu3, isd3 = torch.randn(256, device=dev) * 0.1, torch.rand(256, device=dev) + 0.5
+    red3 = torch.zeros(ops.STATS_COPIES, 256, 2, dtype=torch.float64, device=dev)
+    st3 = torch.zeros(ops.STATS_COPIES, 64, 2, dtype=torch.float64, device=dev)
+    timeit('conv3 dgrad + bn sums', lambda: ops.conv_dgrad(dz, w, (B, H, H, 256), 4, 2, 1, 'c', (z3, sc3, sh3, mu3, isd3, 0.1, red3), {}), fl)
+    timeit('conv3 fwd + stats', lambda: ops.conv_forward(x, w, None, 4, 2, 1, False, st3, False), fl)
+    del z3
     timeit('conv3 wgrad', lambda: ops.conv_wgrad(x, dz, 4, 2, 1), fl)
     del x, dz
 if what in ('bn', 'all'):
