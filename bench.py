@@ -169,8 +169,9 @@ def loss_curve_parity(dev):
     (torch.manual_seed(1234) + the constructor: the product draws the same weights, checked bit for bit against the digests in
     tests/golden/curves_init.npz) on the kernels against the reference's own curve of the same recipe (written by
     tests/golden/make_golden.py from /root/reference): the largest deviation over the 20 steps as a fraction of the curve's range.
-    The recipe has 2^18 first-layer pixels, so the first block takes the patch-moment statistics and the one-pass backward WITHOUT
-    a switch: every kernel class of the 416 x 416 headline step is the one this curve runs on (`same_kernels_as_value`).  The
+    The recipe has 2^18 first-layer pixels, so the first block takes the patch-moment statistics and the one-pass backward, conv_2
+    the F(4x4,3x3) / F(3x3,4x4) kernels and conv_3 the F(4x4,2x2) kernels WITHOUT a switch: every kernel class of the 416 x 416
+    headline step is the one this curve runs on (`same_kernels_as_value`; conv_4 / conv_5 are small here and take F(2x2,2x2)).  The
     closed-form-weight recipe of the same size (tests/golden/curves256.npz) is reported next to it: it concentrates the gradient
     on few activations and measures LeakyReLU kink flips more than arithmetic."""
     import numpy as np
@@ -203,7 +204,11 @@ def loss_curve_parity(dev):
             loss.backward()
             opt.step()
             curve.append(loss.item())
-        gate = bool(ops.USE_CONV1_MOMENTS and ops.USE_CONV1_ONEPASS and ops.USE_WINOGRAD and B * H * H >= ops.CONV1_MOMENTS_MIN_PIXELS)
+        # every kernel class of the headline step runs here too: the first block's moment / one-pass kernels, F(4x4,3x3) / F(3x3,4x4)
+        # on conv_2 and F(4x4,2x2) on conv_3 (conv_4 / conv_5 are below its pixel threshold at this size and take F(2x2,2x2))
+        gate = bool(ops.USE_CONV1_MOMENTS and ops.USE_CONV1_ONEPASS and ops.USE_WINOGRAD and B * H * H >= ops.CONV1_MOMENTS_MIN_PIXELS
+                    and ops.USE_WINOGRAD4 and ops.USE_WINOGRAD4_WGRAD and B * H * H >= ops.WINOGRAD4_MIN_PIXELS
+                    and ops.USE_WINOGRAD4_S2 and ops.USE_WINOGRAD4_S2_DGRAD and B * (H // 2) ** 2 >= ops.WINOGRAD4_S2_MIN_PIXELS)
         return np.array(curve), (H, gg, B), gate
 
     gi, gc, g64 = load_golden('curves_init'), load_golden('curves256'), load_golden('curves64')
@@ -214,7 +219,7 @@ def loss_curve_parity(dev):
     cref, culp, cref64 = gc['dc256_curve'], gc['dc256_curve_ulp'], g64['dc256_curve64']
     cspan = float(cref.max() - cref.min())
     return {'config': 'DarkCapsuleNet %dx%d, n_grid %d, batch %d, the reference\'s default initialisation (seed 1234), Adam lr 1e-3, '
-                      'default kernels (Winograd on, first block: patch-moment statistics + one-pass backward)' % (H, H, gg, B),
+                      'default kernels (first block: patch-moment statistics + one-pass backward; conv_2: F(4x4,3x3) / F(3x3,4x4); conv_3: F(4x4,2x2))' % (H, H, gg, B),
             'steps': 20, 'same_kernels_as_value': gate_open,
             'max_dev_frac_of_range': round(float(np.abs(c - ref).max()) / span, 6),
             'reference_one_ulp_band_frac_of_range': round(float(np.abs(ulp - ref).max()) / span, 6),
