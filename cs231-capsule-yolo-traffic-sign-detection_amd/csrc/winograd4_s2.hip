@@ -41,6 +41,7 @@ struct Wino4S2Args {
   const float* in_scale; const float* in_shift; float in_slope;
   int B, H, W, Cin, Cout, Np, Ho, Wo, tbh, tbw;
   int ntiles;
+  int sgroup;                                   // input gradient: grid tiles per group of 4 channel blocks (see tile_pos)
   float out_slope;
   // input-gradient mode (MODE 1): X = dY [B][H][W][Cin] (H, W, Cin = the layer's output map and channels), Y = dX [B][Hx][Wx][Cx] of the
   // layer, scattered from the (Ho x Wo = Hx/2+1 x Wx/2+1) grid of the space-to-depth view; Cout = Np = 4 Cx; optional BatchNorm-
@@ -148,8 +149,22 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   auto tile_pos = [&](int k) {
     const int id = (int)vid + k * (int)gridDim.x;
     TilePos p;
-    p.nb = id % nblk;
-    int rest = id / nblk;
+    int rest;
+    if constexpr (MODE == 0) {
+      p.nb = id % nblk;
+      rest = id / nblk;
+    } else {
+      // input gradient: N = 4 Cin is 16 channel blocks for conv_3 and each streams its own 426 KB slice of U per tile -- with all 16 on
+      // one XCD (32 consecutive ids = 2 grid tiles x 16 channel blocks) that is 6.8 MB through a 4 MB L2 (measured: 9.6 GB of L2 misses
+      // per launch).  32 consecutive ids are therefore 4 channel blocks x sgroup (8 when it divides the grid tiles) tiles: 1.7 MB of U
+      // and 8 patches of dY per XCD.
+      const int nl = id & 3;
+      int r = id >> 2;
+      const int si = r % a.sgroup; r /= a.sgroup;
+      const int nq = r % (nblk >> 2);
+      p.nb = nq * 4 + nl;
+      rest = (r / (nblk >> 2)) * a.sgroup + si;
+    }
     const int tbx = rest % a.tbw; rest /= a.tbw;
     const int tby = rest % a.tbh;
     p.b = rest / a.tbh; p.Y0 = tby * 16; p.X0 = tbx * 32;
@@ -466,7 +481,9 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
               const bool ok = full || (Yg >= 1 - py && Yg < a.Ho - py && Xg >= 1 - px && Xg < a.Wo - px);
               // (no branch around the load: lanes outside the image read the tensor's first values and never use them)
               const float* zp = ok ? ztile + (4 * (Tj >> 3)) * rowstride + (4 * (Tj & 7)) * colstride + lane_off : a.bn_z;
-              asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(zq[rr][j]) : "v"(zp));
+              // (no `nt`: a wave reads 64 of a line's 128 bytes, the wave next to it the other 64 a moment later -- as a streaming
+              // access the line had left L2 by then: 9.4 GB fetched for 5.67 GB of z, and 0.4 ms of conv_3's 5.6)
+              asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(zq[rr][j]) : "v"(zp));
             }
         }
         f32x2 S[5][4];
@@ -793,6 +810,8 @@ extern "C" int cy_conv4x4s2_winograd4_dgrad(const float* dZ, const float* U, flo
   const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / 64);
   CY_REQUIRE(tiles < (1ll << 31), "cy_conv4x4s2_winograd4_dgrad: too many tiles");
   a.ntiles = (int)tiles;
+  const long long sp_tiles = (long long)B * a.tbh * a.tbw;
+  a.sgroup = sp_tiles % 8 == 0 ? 8 : sp_tiles % 4 == 0 ? 4 : sp_tiles % 2 == 0 ? 2 : 1;
   int dev = 0, ncu = 0;
   hipError_t he = hipGetDevice(&dev);
   if (he == hipSuccess) he = hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
