@@ -259,15 +259,19 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   // ---- transform item: tile (ty, tx), channel pair kg; ROLE 0: rows 0 and 4 of V, ROLE 1: rows 1, 2, 3
   const int tt_ = t & 127;
   // Thread -> item and the slot swizzle follow the LDS lane groups of MI355X_MICROARCH.md (tools/probe/lds_conflicts_wino4s2.py computes all
-  // of this kernel's patterns): a ds_write_b64 serves 16 CONTIGUOUS lanes per cycle on 32 banks, and a lane writes one half of a 16-byte
-  // slot, so 16 contiguous lanes must be 8 slots (mod 8) x both tile halves: lane bits 0 = kg & 1, 1..2 = ttx & 3, 3 = tile half, and
-  // the slot is XORed with 12 (kg & 1) -- bit 2 makes the two kg of a group different slots mod 8, bit 3 keeps the ds_read_b128 of the
-  // fragments conflict-free (its 16-lane groups pair lanes {0-3, 12-15} of k-group 2j with lanes {4-11} of k-group 2j + 1: XOR 12 maps
-  // {4..11} onto itself).  The first version (lane = kg + 4 ttx + 32 tty, XOR 4 kg) had both at 2-way: 45 % of the LDS cycles were
-  // conflict cycles (SQ_LDS_BANK_CONFLICT).  The transform's own reads stay 2-way (16-float tile pitch: only 32 banks reachable).
-  const int kg = (tt_ & 1) | (((tt_ >> 4) & 1) << 1), ttx = ((tt_ >> 1) & 3) | (((tt_ >> 5) & 1) << 2), tty = (((tt_ >> 3) & 1) << 1) | ((tt_ >> 6) & 1);
+  // of this kernel's patterns).  ds_write_b64 / ds_write2st64_b64 and the ds_read2_b64 hipcc merges the transform's reads into serve 16
+  // CONTIGUOUS lanes per cycle on 32 banks:
+  //   * a lane stores one half of a 16-byte slot, so 16 contiguous lanes must be 8 slots (mod 8) x both tile halves: lane bits 0..1 = kg,
+  //     2 = ttx & 1, 3 = tile half, slot XOR 2 kg (bits 1, 2 of the slot from kg, bit 0 from ttx);
+  //   * the raw reads (16-float tile pitch, k-quads 4 floats apart mod 32) reach 16 of 32 banks whatever the map: 2-way, as little as
+  //     possible, needs kg and ttx & 1 inside the 16 lanes;
+  //   * the fragments' ds_read_b128 pairs lanes {0-3, 12-15} of k-group 2j with lanes {4-11} of k-group 2j + 1 on 64 banks: XOR 2 maps
+  //     {4..11} onto itself and XOR 4 / 6 swap the two sets for the pair (2, 3): conflict-free.
+  // (lane = kg + 4 ttx + 32 tty with XOR 4 kg, the first version, had the stores and, by the table, the fragment reads at 2-way:
+  // SQ_LDS_BANK_CONFLICT 45 % of the LDS cycles; time was the same -- the LDS array is 25 % busy here.)
+  const int kg = tt_ & 3, ttx = ((tt_ >> 2) & 1) | (((tt_ >> 4) & 3) << 1), tty = (((tt_ >> 3) & 1) << 1) | ((tt_ >> 6) & 1);
   const int tbase = ((kg >> 1) * H4_RAWP + (4 * tty) * H4_PC + 4 * ttx) * 4 + 2 * (kg & 1);
-  const int tslot = ((tty & 1) * 8 + ttx) ^ (12 * (kg & 1));
+  const int tslot = ((tty & 1) * 8 + ttx) ^ (2 * kg);
   const int vdst = (kg * 16 + tslot) * 4 + (tty >> 1) * 2;      // + pos * 256
   const f32x2 k2 = {2.f, 2.f}, km2 = {-2.f, -2.f}, k3 = {3.f, 3.f};
   constexpr int NR = ROLE == 0 ? 2 : 3;         // rows of this role; row index of its k-th row:
@@ -372,7 +376,7 @@ __device__ __forceinline__ void h4_run(const Wino4S2Args& a, float* smem) {
   for (int q = 0; q < H4_NP; ++q) h4_bload<0>(bq[q], up_cur + (q & 3) * 1024, ulane[q >> 2]);
 
   const int kgl = lane >> 4, ml = lane & 15;
-  const int fragA = (kgl * 16 + (ml ^ (12 * (kgl & 1)))) * 4;
+  const int fragA = (kgl * 16 + (ml ^ (2 * kgl))) * 4;
   f32x4 fa[5];                                  // A fragments of positions p % 5 (25 positions: the ring's phase is the same in every chunk)
   fa[0] = *(const f32x4*)(Vs + fragA);
   fa[1] = *(const f32x4*)(Vs + fragA + 256);

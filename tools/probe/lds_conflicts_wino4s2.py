@@ -35,24 +35,24 @@ def lanes(wv):
         if VARIANT == 1:
             yield l, tt & 3, (tt >> 2) & 7, tt >> 5        # lane, kg, ttx, tty
         else:
-            yield l, (tt & 1) | (((tt >> 4) & 1) << 1), ((tt >> 1) & 3) | (((tt >> 5) & 1) << 2), (((tt >> 3) & 1) << 1) | ((tt >> 6) & 1)
+            yield l, tt & 3, ((tt >> 2) & 1) | (((tt >> 4) & 3) << 1), (((tt >> 3) & 1) << 1) | ((tt >> 6) & 1)
 
 
 def swz(kg):
-    return (kg << 2) if VARIANT == 1 else 12 * (kg & 1)
+    return (kg << 2) if VARIANT == 1 else 2 * kg
 
 
 def report():
     # transform reads of the raw patch: thread (kg, ttx, tty) reads float2 of pixel (4 tty + r, 4 ttx + c), k-quad kg >> 1, half kg & 1
-    tot = ideal = 0
+    tot = ideal = tot2 = 0
     for wv in (0, 1):
         for r in range(5):
             for c in range(5):
                 ad = [0] * 64
                 for l, kg, ttx, tty in lanes(wv):
                     ad[l] = ((kg >> 1) * RAWP + (4 * tty + r) * PC + 4 * ttx + c) * 4 + 2 * (kg & 1)
-                tot += cycles(ad, 2, G2x32, 64); ideal += 2
-    print('transform reads (ds_read_b64)    : %.2f cycles per instruction (conflict-free 2)' % (2.0 * tot / ideal))
+                tot += cycles(ad, 2, G2x32, 64); ideal += 2; tot2 += cycles(ad, 2, G4x16, 32)
+    print('transform reads as ds_read_b64   : %.2f cycles per instruction (conflict-free 2); as one access of the ds_read2_b64 hipcc emits: %.2f (conflict-free 4)' % (2.0 * tot / ideal, 2.0 * tot2 / ideal))
     # V stores: [pos][kg][16 tile slots][tile half][2 k-steps], slot = ((tty & 1) * 8 + ttx) ^ swz(kg)
     for wv in (0, 1):
         ad = [0] * 64
