@@ -1137,3 +1137,46 @@ def test_conv3x3_winograd4_wgrad_with_fused_batchnorm_backward(case):
     finally:
         ops.USE_WINOGRAD4_WGRAD = old
     close(dw, dw_ref, 6e-5, 6e-5 * dw_ref.abs().max().item())
+
+
+def test_round3_winograd_kernels_repeat_bit_for_bit(monkeypatch):
+    """The F(4x4,3x3) / F(3x3,4x4) / F(4x4,2x2) kernels add their partial sums in a fixed order (tile ranges, chunk order) and read
+    every hand-waited register behind a sufficient wait: the same inputs give the same bits, run after run (the double atomics of the
+    BatchNorm sums are the one documented exception and are not compared).  tools/check_determinism.py runs more shapes."""
+    from capsyolo_amd import ops
+    monkeypatch.setattr(ops, 'WINOGRAD4_MIN_PIXELS', 0)
+    monkeypatch.setattr(ops, 'WINOGRAD4_S2_MIN_PIXELS', 0)
+    B, H = 3, 48
+    x = rnd((B, H, H, 128), 301).to(dev())
+    w3 = rnd((128, 128, 3, 3), 302, 0.03).to(dev())
+    dz3 = rnd((B, H, H, 128), 303).to(dev())
+    w4 = rnd((64, 128, 4, 4), 304, 0.03).to(dev())
+    dz4 = rnd((B, H // 2, H // 2, 64), 305).to(dev())
+    z = rnd((B, H, H, 128), 306).to(dev())
+    sc, sh = (rnd((128,), 307, 0.3) + 1.0).to(dev()), rnd((128,), 308, 0.5).to(dev())
+    mu, isd = rnd((128,), 309, 0.2).to(dev()), (rnd((128,), 310, 0.1).abs() + 0.8).to(dev())
+
+    def bn_dgrad():
+        red = torch.zeros((ops.STATS_COPIES, 128, 2), dtype=torch.float64, device=dev())
+        return ops.conv_dgrad(dz4, w4, (B, H, H, 128), 4, 2, 1, 'c', (z, sc, sh, mu, isd, 0.1, red), {})
+    cases = {
+        'F(4x4,3x3) forward': lambda: ops.conv_forward(x, w3, None, 3, 1, 1),
+        'F(4x4,3x3) input gradient': lambda: ops.conv_dgrad(dz3, w3, (B, H, H, 128), 3, 1, 1),
+        'F(3x3,4x4) weight gradient': lambda: ops.conv_wgrad(x, dz3, 3, 1, 1),
+        'F(4x4,2x2) forward': lambda: ops.conv_forward(x, w4, None, 4, 2, 1),
+        'F(4x4,2x2) forward, input affine': lambda: ops.conv_forward(x, w4, None, 4, 2, 1, False, None, False, 'c', (sc, sh, 0.1)),
+        'F(4x4,2x2) input gradient': lambda: ops.conv_dgrad(dz4, w4, (B, H, H, 128), 4, 2, 1),
+        'F(4x4,2x2) input gradient with the BatchNorm sums (stored gradient)': bn_dgrad,
+    }
+    ops.timer.reset()
+    ops.timer.enabled = True
+    try:
+        for name, fn in cases.items():
+            first = fn()
+            for _ in range(3):
+                assert torch.equal(fn(), first), name
+    finally:
+        ops.timer.enabled = False
+    keys = ops.timer.summary()
+    for pre in ('conv_wino4_fwd/', 'conv_wino4_dgrad/', 'conv_wino4_wgrad/', 'conv_wino42_fwd/', 'conv_wino42_dgrad/'):
+        assert any(k.startswith(pre) for k in keys), pre
