@@ -61,6 +61,11 @@ struct Geo {
   int K;                                            // TH * TW * Cin
   int ntm, ntn;                                     // tiles along M and N
   long long* prof;                                  // developer instrumentation (CY_BF16_PROF): per block cycles of loop / epilogue / waits
+  // BNF (input gradient, bf16 output): the output is dA of the producer block; its raw convolution output z (bf16, the layout of Y)
+  // and BatchNorm constants come in, d = dA * lrelu'(z * scale + shift) is what is stored, and sum d, sum d * xhat go to
+  // bn_red[CY_STATS_COPIES][N][2] (the fp32 kernels' cy_conv_gemm_t.bn_* contract)
+  const u16* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; double* bn_red;
+  float bn_slope;
 };
 
 // BM x BN block tile on WM x WN waves; wave tile (BM / WM) x (BN / WN) = MI x NI tiles of 32x32.
@@ -74,8 +79,9 @@ struct Geo {
 //    16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7) -- applied on the DMA's per-lane SOURCE address and on
 //    the fragment reads -- so that the 16 lanes of a ds_read_b128 group fall on 16 different bank groups.
 //  * padding pixels and rows past M read 16 zero bytes (conv_bf16_zero16): the DMA is unconditional.
-template <int BM, int BN, int WM, int WN, bool OUT_F32>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf16_kernel(Geo a) {
+  static_assert(!(BNF && OUT_F32), "the fused BatchNorm-backward sums are built for the bf16 output");
   constexpr int NT = 64 * WM * WN;
   constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);                // 32x32 tiles per wave
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, BUF_BYTES = A_BYTES + B_BYTES;
@@ -275,6 +281,31 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
     const int cq = lane % LPR, rsub = lane / LPR;
     const int nst = n0 + wn * WC + cq * CPL;
     const bool full_rows = (long long)(m_tile + 1) * BM <= a.M;          // uniform: no row of the tile lies past M
+    // BNF: the lane's 8 channels' constants, its running sums, and the z values of a slice requested ONE SLICE AHEAD of their use
+    constexpr int NIT = 16 / RPI;                   // store instructions per slice
+    float bsc[8], bsh[8], bis[8], bnm[8], b1[8], b2[8];
+    constexpr int ZAH = 1;                          // slices of z in flight ahead of the one being stored (2: no faster -- the launch is HBM-bound)
+    u32x4_t zq[ZAH + 1][NIT];
+    auto zreq = [&](int slice, u32x4_t (&dst)[NIT]) {              // slice = mi * 2 + hf
+      const int rb = (wm * MI + (slice >> 1)) * 32 + 16 * (slice & 1);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const long long off = rowoff[rb + it * RPI + rsub];
+        // (rows past M and padded channels read the tensor's first bytes and never use them: no branch around the load)
+        const u16* zp = (off >= 0 && nst < a.N) ? a.bn_z + off + nst : a.bn_z;
+        dst[it] = __builtin_nontemporal_load((const u32x4_t*)zp);
+      }
+    };
+    if constexpr (BNF) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int n = nst + e < a.N ? nst + e : 0;
+        bsc[e] = a.bn_scale[n]; bsh[e] = a.bn_shift[n]; bis[e] = a.bn_invstd[n]; bnm[e] = -a.bn_mean[n] * bis[e];
+        b1[e] = 0.f; b2[e] = 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < ZAH && q < MI * 2; ++q) zreq(q, zq[q]);
+    }
     // (the bias is read ONCE per tile, above: loaded inside these loops it put a global-memory round trip in front of each of
     // the 16 slices -- 16.7k of the tile's 90k cycles at conv_2)
 #pragma unroll
@@ -318,13 +349,39 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
           if (a.prof) pe2 = (long long)__builtin_amdgcn_s_memtime();
           __builtin_amdgcn_sched_barrier(0);
         }
+        if constexpr (BNF) {                        // the next slice's z: a slice of work (and the SIMD's other wave) ahead of its use
+          if (mi * 2 + hf + ZAH < MI * 2) zreq(mi * 2 + hf + ZAH, zq[(mi * 2 + hf + ZAH) % (ZAH + 1)]);
+        }
 #pragma unroll
         for (int it = 0; it < 16 / RPI; ++it) {
           const int row_l = it * RPI + rsub;
           const long long off = rowoff[rbase + row_l];
           if (off >= 0 && nst < a.N) {
             const float* src = ow + row_l * WC + cq * CPL;
-            if (OUT_F32) {
+            if constexpr (BNF) {
+              const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
+              const u32x4_t zz = zq[(mi * 2 + hf) % (ZAH + 1)][it];
+              float d[8];
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = (e & 1) ? __uint_as_float(zz[e >> 1] & 0xffff0000u) : __uint_as_float(zz[e >> 1] << 16);
+                const float v = e < 4 ? v0[e] : v1[e - 4];
+                const float y = __builtin_fmaf(z, bsc[e], bsh[e]);
+                d[e] = y > 0.f ? v : v * a.bn_slope;
+              }
+              u32x4_t o;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) o[e] = (unsigned)f2bf(d[2 * e]) | ((unsigned)f2bf(d[2 * e + 1]) << 16);
+              // the sums are those of the STORED (bf16-rounded) gradient: what cy_bn_bwd_reduce_bf16 would read back
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float z = (e & 1) ? __uint_as_float(zz[e >> 1] & 0xffff0000u) : __uint_as_float(zz[e >> 1] << 16);
+                const float dr = (e & 1) ? __uint_as_float(o[e >> 1] & 0xffff0000u) : __uint_as_float(o[e >> 1] << 16);
+                b1[e] += dr;
+                b2[e] = __builtin_fmaf(dr, __builtin_fmaf(z, bis[e], bnm[e]), b2[e]);
+              }
+              CY_BF_ST(o, (u32x4_t*)((u16*)a.Y + off + nst));
+            } else if (OUT_F32) {
               CY_BF_ST(*(const f32x4*)src, (f32x4*)((float*)a.Y + off + nst));
             } else {
               const f32x4 v0 = *(const f32x4*)src, v1 = *(const f32x4*)(src + 4);
@@ -361,6 +418,33 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
         atomicAdd(st + 2 * (n0 + t), s2);
         atomicAdd(st + 2 * (n0 + t) + 1, q2);
       }
+    }
+    if constexpr (BNF) {
+      // lanes that share cq (the same 8 channels) differ in the lane bits above log2(LPR): fold those, then the waves along M through LDS
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int msk = LPR; msk < 64; msk <<= 1) { b1[e] += __shfl_xor(b1[e], msk, 64); b2[e] += __shfl_xor(b2[e], msk, 64); }
+      __syncthreads();                              // every wave is done with its `ow` slice
+      float* red = scratch;                         // [WM][BN][2]
+      if (lane < LPR) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int col = wn * WC + cq * CPL + e;
+          red[(wm * BN + col) * 2 + 0] = b1[e];
+          red[(wm * BN + col) * 2 + 1] = b2[e];
+        }
+      }
+      __syncthreads();
+      if (t < BN && n0 + t < a.N) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { s1 += (double)red[(w * BN + t) * 2]; s2 += (double)red[(w * BN + t) * 2 + 1]; }
+        double* rd = a.bn_red + (size_t)(m_tile % CY_STATS_COPIES) * a.N * 2;
+        atomicAdd(rd + 2 * (n0 + t), s1);
+        atomicAdd(rd + 2 * (n0 + t) + 1, s2);
+      }
+      __syncthreads();                              // (the scratch is the next tile's operand buffer after the next K step)
     }
     slot ^= 1;
     if (a.prof && t == 0) {
@@ -417,10 +501,10 @@ __global__ void cast_kernel_b2f(const u16* __restrict__ in, float* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false>
 int launch(Geo g, hipStream_t s) {
   const size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  int rc = cy_allow_lds(conv_bf16_kernel<BM, BN, WM, WN, OUT_F32>, lds);
+  int rc = cy_allow_lds(conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF>, lds);
   if (rc) return rc;
   g.ntm = (int)cy_ceil_div(g.M, BM);
   g.ntn = (int)cy_ceil_div(g.N, BN);
@@ -430,29 +514,29 @@ int launch(Geo g, hipStream_t s) {
   g.prof = nullptr;
   static const bool prof_on = getenv("CY_BF16_PROF") != nullptr;      // developer instrumentation: synchronous, prints per launch
   if (prof_on) {
-    hipMalloc(&g.prof, nblk * 64);
-    hipMemsetAsync(g.prof, 0, nblk * 64, s);
+    (void)hipMalloc(&g.prof, nblk * 64);
+    (void)hipMemsetAsync(g.prof, 0, nblk * 64, s);
   }
-  conv_bf16_kernel<BM, BN, WM, WN, OUT_F32><<<nblk, 64 * WM * WN, lds, s>>>(g);
+  conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF><<<nblk, 64 * WM * WN, lds, s>>>(g);
   if (prof_on) {
-    hipStreamSynchronize(s);
+    (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nblk * 64);
-    hipMemcpy(h, g.prof, nblk * 64, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(h, g.prof, nblk * 64, hipMemcpyDeviceToHost);
     double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (unsigned i = 0; i < nblk; ++i) for (int k = 0; k < 8; ++k) v[k] += h[8 * i + k];
     const double nt = v[3];
     fprintf(stderr, "conv_bf16<%d,%d> K steps %d: per tile loop %.0f ticks (of which top-of-step wait+barrier %.0f), epilogue %.0f = barrier %.0f + first slice %.0f + ... + rest %.0f; of the top-of-step time, vmcnt wait %.0f; tiles %.0f\n",
             BM, BN, g.K / BK, v[0] / nt, v[2] / nt, v[1] / nt, v[4] / nt, v[5] / nt, v[7] / nt, v[6] / nt, nt);
-    free(h); hipFree(g.prof);
+    free(h); (void)hipFree(g.prof);
   }
   return 0;
 }
-template <bool OUT_F32>
+template <bool OUT_F32, bool BNF = false>
 int launch_n(const Geo& g, hipStream_t s) {
-  if (g.N % 256 == 0) return launch<256, 256, 2, 4, OUT_F32>(g, s);
-  if (g.N % 128 == 0) return launch<512, 128, 4, 2, OUT_F32>(g, s);   // the same 128 x 64 wave tiles (256 x 128 had 16 MFMAs per wave and K step: 0.30)
-  if (g.M >= 512 * 256) return launch<512, 64, 8, 1, OUT_F32>(g, s);     // N = 64 (conv_3): 8 waves of 64 x 64 instead of 4 of 32 x 64
-  return launch<128, 64, 4, 1, OUT_F32>(g, s);
+  if (g.N % 256 == 0) return launch<256, 256, 2, 4, OUT_F32, BNF>(g, s);
+  if (g.N % 128 == 0) return launch<512, 128, 4, 2, OUT_F32, BNF>(g, s);   // the same 128 x 64 wave tiles (256 x 128 had 16 MFMAs per wave and K step: 0.30)
+  if (g.M >= 512 * 256) return launch<512, 64, 8, 1, OUT_F32, BNF>(g, s);     // N = 64 (conv_3): 8 waves of 64 x 64 instead of 4 of 32 x 64
+  return launch<128, 64, 4, 1, OUT_F32, BNF>(g, s);
 }
 
 }  // namespace
@@ -477,7 +561,8 @@ extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* str
   CY_REQUIRE(a->Cin % 64 == 0 && a->N % 64 == 0, "cy_conv_gemm_bf16: Cin=%d and N=%d must be multiples of 64", a->Cin, a->N);
   CY_REQUIRE(a->xs_c == 1 && a->xs_x == a->Cin && a->xs_y == (long long)a->Wi * a->Cin &&
              a->xs_b == (long long)a->Hi * a->Wi * a->Cin, "cy_conv_gemm_bf16: X must be plain NHWC");
-  CY_REQUIRE(a->bn_red == nullptr, "cy_conv_gemm_bf16: the fused BatchNorm-backward epilogue exists in the fp32 kernel only");
+  CY_REQUIRE(a->bn_red == nullptr || (!out_f32 && a->bn_z && a->bn_scale && a->bn_shift && a->bn_mean && a->bn_invstd && (((uintptr_t)a->bn_z) & 15) == 0),
+             "cy_conv_gemm_bf16: the fused BatchNorm-backward sums need the bf16 output, bn_z (bf16, 16-byte aligned) and scale / shift / mean / invstd");
   CY_REQUIRE((((uintptr_t)a->X | (uintptr_t)a->Wp | (uintptr_t)a->Y) & 15) == 0, "cy_conv_gemm_bf16: pointers must be 16-byte aligned");
   Geo g;
   g.X = (const u16*)a->X; g.Wp = (const u16*)a->Wp; g.Y = (void*)a->Y; g.bias = a->bias; g.stats = a->stats;
@@ -491,7 +576,9 @@ extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* str
   g.K = a->TH * a->TW * a->Cin;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  rc = out_f32 ? launch_n<true>(g, s) : launch_n<false>(g, s);
+  g.bn_z = (const u16*)a->bn_z; g.bn_scale = a->bn_scale; g.bn_shift = a->bn_shift; g.bn_mean = a->bn_mean; g.bn_invstd = a->bn_invstd;
+  g.bn_red = a->bn_red; g.bn_slope = a->bn_slope;
+  rc = out_f32 ? launch_n<true>(g, s) : (a->bn_red != nullptr ? launch_n<false, true>(g, s) : launch_n<false>(g, s));
   if (rc) return rc;
   CY_LAUNCH_CHECK("cy_conv_gemm_bf16");
   return 0;

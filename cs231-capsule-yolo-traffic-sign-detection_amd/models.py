@@ -82,6 +82,7 @@ class FusedBackbone(nn.Sequential):
                                                  'for conv -> BatchNorm -> LeakyReLU blocks only' % (nm, type(m).__name__))
         convs = [i for i, m in enumerate(mods) if isinstance(m, HipConv2d)]
         first = True
+        holder = None                            # producer block -> consumer block: what the fused BatchNorm-backward sums need
         for n, i in enumerate(convs):
             m = mods[i]
             bn, act, _ = self._triple(mods, i)
@@ -101,6 +102,8 @@ class FusedBackbone(nn.Sequential):
             cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, False, bn, slope, names[i])
             cfg.in_f32 = (n == 1) and x.dtype == torch.float32   # (a first block without BatchNorm hands over fp32)
             cfg.out_f32 = (n == len(convs) - 1)
+            cfg.in_holder, cfg.out_holder = holder, {}
+            holder = cfg.out_holder
             x = ops.conv_block_bf16(x, m.weight, m.bias, bn.weight, bn.bias, cfg)
         return x
 

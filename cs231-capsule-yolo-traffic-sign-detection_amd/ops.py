@@ -734,9 +734,17 @@ def conv_forward_bf16(x, weight, bias, k, stride, pad, stats=None, tag='conv', l
     return z
 
 
-def conv_dgrad_bf16(dz, weight, in_shape, k, stride, pad, out_f32=False, tag='conv'):
-    """dx [B,Hi,Wi,Cin] (bf16, or fp32 for an fp32 producer) from dz (bf16): one GEMM per output-parity class."""
+FUSE_BN_BWD_REDUCE_BF16 = True     # bf16 path: the producer block's BatchNorm-backward sums out of the consumer's input-gradient epilogue
+
+
+def conv_dgrad_bf16(dz, weight, in_shape, k, stride, pad, out_f32=False, tag='conv', bn_fuse=None):
+    """dx [B,Hi,Wi,Cin] (bf16, or fp32 for an fp32 producer) from dz (bf16): one GEMM per output-parity class.
+    bn_fuse = (z bf16, scale, shift, mean, invstd, slope, red[STATS_COPIES][Cin][2]) of the PRODUCER block (bf16 output only): the
+    epilogues store d = dx * lrelu'(z * scale + shift) -- the premasked gradient -- and add sum d, sum d * xhat of the stored
+    (bf16-rounded) values to red, all parity classes together (cy_conv_gemm_t.bn_*)."""
     dz, weight = _bf(dz, 'grad'), _f32(weight, 'conv weight')
+    if bn_fuse is not None and out_f32:
+        raise _lib.HipExtensionError('conv_dgrad_bf16: the fused BatchNorm-backward sums are built for the bf16 output')
     B, Hi, Wi, Cin = in_shape
     _, Ho, Wo, Cout = dz.shape
     st = _stream()
@@ -750,6 +758,10 @@ def conv_dgrad_bf16(dz, weight, in_shape, k, stride, pad, out_f32=False, tag='co
                      xs_b=Ho * Wo * Cout, xs_y=Wo * Cout, xs_x=Cout, xs_c=1, B=B, Hi=Ho, Wi=Wo, Cin=Cout,
                      Ho=c['Ho'], Wo=c['Wo'], N=Cin, TH=c['TH'], TW=c['TW'], in_stride=1, dy0=c['dy0'], dx0=c['dx0'],
                      dstep=c['dstep'], Hy=Hi, Wy=Wi, out_stride=c['out_stride'], out_oy=c['out_oy'], out_ox=c['out_ox'], act=0)
+        if bn_fuse is not None:
+            bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
+            a.bn_z, a.bn_scale, a.bn_shift = _bf(bz, 'producer z').data_ptr(), bsc.data_ptr(), bsh.data_ptr()
+            a.bn_mean, a.bn_invstd, a.bn_red, a.bn_slope = bmu.data_ptr(), bis.data_ptr(), bred.data_ptr(), float(bsl)
         with timer.range('conv_bf16_dgrad/' + tag):
             call('cy_conv_gemm_bf16', C.byref(a), 1 if out_f32 else 0, st)
     return dx
@@ -819,6 +831,12 @@ class _ConvBlockBF16(torch.autograd.Function):
         out = torch.empty(z.shape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=z.device)
         call('cy_affine_act_bf16', _ptr(z), _ptr(out), _ptr(scale), _ptr(shift), float(cfg.slope), P, N, 1 if out_f32 else 0, st)
         ctx.save_for_backward(x, weight, z, scale, shift, mean, invstd)
+        h = getattr(cfg, 'out_holder', None)
+        if h is not None:
+            # what the CONSUMER block's input-gradient epilogue needs for this block's BatchNorm-backward sums (bf16 output only)
+            h.clear()
+            if bn.training and not out_f32:
+                h.update(z=z, scale=scale, shift=shift, mean=mean, invstd=invstd, slope=float(cfg.slope), red=None)
         return out
 
     @staticmethod
@@ -831,9 +849,16 @@ class _ConvBlockBF16(torch.autograd.Function):
         N, P = weight.shape[0], ctx.P
         da_f32 = da.dtype == torch.float32
         da = _f32(da, 'grad') if da_f32 else _bf(da, 'grad')
-        red = _empty((N, 2), weight, torch.float64)
-        call('cy_bn_bwd_reduce_bf16', _ptr(z), _ptr(da), 1 if da_f32 else 0, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
-             float(cfg.slope), _ptr(red), P, N, st)
+        slope = float(cfg.slope)
+        ho = getattr(cfg, 'out_holder', None)
+        if ho is not None and ho.get('red') is not None and not da_f32:
+            red = ho['red']                    # summed by the consumer block's input-gradient epilogues, which also stored da premasked
+            ho['red'] = None
+            slope = 1.0
+        else:
+            red = _empty((N, 2), weight, torch.float64)
+            call('cy_bn_bwd_reduce_bf16', _ptr(z), _ptr(da), 1 if da_f32 else 0, _ptr(scale), _ptr(shift), _ptr(mean), _ptr(invstd),
+                 slope, _ptr(red), P, N, st)
         dist, world = _sync_world()
         if dist is not None:
             call('cy_bn_red_fold', _ptr(red), 1, 1.0 / world, _ptr(red), None, None, N, st)
@@ -841,12 +866,22 @@ class _ConvBlockBF16(torch.autograd.Function):
         dz = torch.empty_like(z)
         dgamma, dbeta = _empty((N,), weight), _empty((N,), weight)
         call('cy_bn_bwd_apply_bf16', _ptr(z), _ptr(da), 1 if da_f32 else 0, _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean),
-             _ptr(invstd), float(cfg.slope), _ptr(red), _ptr(dgamma), _ptr(dbeta), P, N, st)
+             _ptr(invstd), slope, _ptr(red), _ptr(dgamma), _ptr(dbeta), P, N, st)
         dW = conv_wgrad_bf16(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.name)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = conv_dgrad_bf16(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, bool(getattr(cfg, 'in_f32', False)),
-                                 cfg.name)
+            in_f32 = bool(getattr(cfg, 'in_f32', False))
+            hi = getattr(cfg, 'in_holder', None)
+            fuse = None
+            if (FUSE_BN_BWD_REDUCE_BF16 and hi is not None and hi.get('z') is not None and not in_f32
+                    and tuple(hi['z'].shape) == tuple(x.shape)):
+                Cin = x.shape[3]
+                bred = zero_pool.take((STATS_COPIES, Cin, 2), torch.float64, x.device)
+                fuse = (hi['z'], hi['scale'], hi['shift'], hi['mean'], hi['invstd'], hi['slope'], bred)
+            dx = conv_dgrad_bf16(dz, weight, tuple(x.shape), cfg.k, cfg.stride, cfg.pad, in_f32, cfg.name, fuse)
+            if fuse is not None:
+                hi['red'] = _empty((x.shape[3], 2), weight, torch.float64)
+                call('cy_bn_red_fold', _ptr(fuse[6]), STATS_COPIES, 1.0, _ptr(hi['red']), None, None, x.shape[3], st)
         dbias = _const_zeros(N, weight) if ctx.has_bias else None       # in front of BatchNorm: analytically zero
         return dx, dW, dbias, dgamma, dbeta, None
 

@@ -51,7 +51,9 @@ typedef struct {
    * accumulates that BatchNorm's backward sums over the pixels it stores -- per channel n:
    *   d = Y * (bn_z*scale+shift > 0 ? 1 : bn_slope),  bn_red[copy][n][0] += d,  bn_red[copy][n][1] += d * (bn_z - mean) * invstd
    * (bn_red[CY_STATS_COPIES][N][2] doubles, zeroed by the caller) -- which replaces the cy_bn_bwd_reduce pass
-   * (loss_fns / autograd of models.py:349-351).  All NULL / 0 when unused. */
+   * (loss_fns / autograd of models.py:349-351).  All NULL / 0 when unused.
+   * cy_conv_gemm_bf16 (bf16 output only): bn_z points to bf16 values, and the kernel STORES d (the premasked gradient, rounded to
+   * bf16) and sums the stored values: the producer's cy_bn_bwd_apply_bf16 then runs with slope 1. */
   const float* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd;
   double* bn_red;
   float bn_slope;

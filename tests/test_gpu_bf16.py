@@ -73,6 +73,40 @@ def test_conv_bf16_fwd_dgrad_wgrad(case):
     assert rel_l2(dw, wd.grad) < 2e-5            # exact products, fp32 accumulation, fp32 result
 
 
+@pytest.mark.parametrize('case', BF16_CASES + [(4, 64, 40, 36, 64, 4, 2), (2, 256, 44, 44, 128, 3, 1)])
+def test_conv_dgrad_bf16_with_fused_batchnorm_backward_sums(case):
+    """The bf16 input-gradient kernel's optional BatchNorm-backward sums of the PRODUCER block (ops.conv_dgrad_bf16 bn_fuse): the
+    stored gradient is bf16(dx * lrelu'(z * scale + shift)) with dx the fp32 accumulator (= the out_f32 launch), and the sums are
+    those of the STORED values -- what cy_bn_bwd_reduce_bf16 would compute from them with slope 1 -- over all parity classes."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import call
+    B, Cin, H, W, Cout, k, s = case
+    Ho, Wo = (H + 2 - k) // s + 1, (W + 2 - k) // s + 1
+    w = rnd_bf((Cout, Cin, k, k), 12, (1.0 / (Cin * k * k)) ** 0.5).to(dev())
+    gz = rnd_bf((B, Ho, Wo, Cout), 14).to(dev()).to(BF)
+    z = rnd_bf((B, H, W, Cin), 15).to(dev()).to(BF)
+    g = torch.Generator().manual_seed(16)
+    sc, sh = (torch.rand(Cin, generator=g) + 0.5).to(dev()), (torch.randn(Cin, generator=g) * 0.5).to(dev())
+    mu, isd = (torch.randn(Cin, generator=g) * 0.2).to(dev()), (torch.rand(Cin, generator=g) + 0.5).to(dev())
+    red = torch.zeros(ops.STATS_COPIES, Cin, 2, dtype=torch.float64, device=dev())
+    d = ops.conv_dgrad_bf16(gz, w, (B, H, W, Cin), k, s, 1, False, 'c', (z, sc, sh, mu, isd, 0.1, red))
+    dx32 = ops.conv_dgrad_bf16(gz, w, (B, H, W, Cin), k, s, 1, True)
+    assert d.dtype == BF
+    y = torch.addcmul(sh, z.float(), sc)
+    ref = torch.where(y > 0, dx32, dx32 * 0.1).to(BF)
+    # (the kernel forms y with one fused multiply-add: a pre-activation within an ulp of zero may take the other branch)
+    differ = (d != ref)
+    assert int(differ.sum()) <= max(2, d.numel() // 100000), int(differ.sum())
+    assert bool((y.abs()[differ] < 1e-5).all())
+    # the sums against the reduce kernel run on the stored gradient (already masked: slope 1)
+    want = torch.zeros(Cin, 2, dtype=torch.float64, device=dev())
+    call('cy_bn_bwd_reduce_bf16', z.data_ptr(), d.data_ptr(), 0, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1.0,
+         want.data_ptr(), B * H * W, Cin, torch.cuda.current_stream().cuda_stream)
+    got = red.sum(0)
+    scale_ = want.abs().max(dim=0).values.clamp(min=1e-30)
+    assert float(((got - want).abs() / scale_).max()) < 1e-5, ((got - want).abs() / scale_).max()
+
+
 def test_bn_act_bf16_kernels():
     """affine_act / bn_bwd_reduce / bn_bwd_apply on bf16 tensors vs the formulas in fp64."""
     from capsyolo_amd._lib import call
