@@ -119,6 +119,7 @@ _SIGS = {
     'cy_zero_bytes': [_P, _L, _P],
     'cy_conv_bf16_pack_weights': [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'cy_conv_gemm_bf16': [C.POINTER(ConvGemm), _I, _P],
+    'cy_conv_gemm_bf16_classes': [C.POINTER(ConvGemm), _I, _I, _P],
     'cy_conv_wgrad_bf16': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'cy_affine_act_bf16': [_P, _P, _P, _P, _F, _L, _I, _I, _P],
     'cy_bn_bwd_reduce_bf16': [_P, _P, _I, _P, _P, _P, _P, _F, _P, _L, _I, _P],

@@ -66,6 +66,12 @@ struct Geo {
   // bn_red[CY_STATS_COPIES][N][2] (the fp32 kernels' cy_conv_gemm_t.bn_* contract)
   const u16* bn_z; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_invstd; double* bn_red;
   float bn_slope;
+  // ncls > 1: ONE launch for the output-parity classes of a strided input gradient (cy_conv_gemm_bf16_classes): tile = (m tile, n tile,
+  // class) with the class fastest, so that the blocks working on the classes of one pixel tile read the same rows of X at the same
+  // time (separate launches read X once per class from HBM: 4 x 1.5 GB at conv_3 / 608^2).  Classes share every field but these:
+  int ncls;
+  int c_dy0[4], c_dx0[4], c_oy[4], c_ox[4];
+  const u16* c_wp[4];
 };
 
 // BM x BN block tile on WM x WN waves; wave tile (BM / WM) x (BN / WN) = MI x NI tiles of 32x32.
@@ -95,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
   const int li = lane & 31, lh = lane >> 5;
   const int srow = t >> 3;                                               // row of a staging round this thread's lane fills
   const int chunk_l = (t & 7) ^ ((srow >> 1) & 7);                       // logical 16-byte chunk behind its physical chunk t & 7
-  const int ntiles = a.ntm * a.ntn;
+  const int ntiles = a.ntm * a.ntn * a.ncls;
   const int KT = a.K / BK;                          // K steps: taps x (Cin / 64)
   const int cpt = a.Cin / BK;                       // K steps per tap
 
@@ -107,8 +113,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
   // (M < 2^31 is checked by the launcher: pixel indices are 32-bit here, one division pair per thread and tile -- the 64-bit
   // divisions of the first version were ~1500 instructions per tile in front of the last K step's MFMAs)
   auto set_tile = [&](int tile, int slot) {
-    const unsigned m0 = (unsigned)(tile / a.ntn) * BM;
-    const int n0 = (tile % a.ntn) * BN;
+    const int cls = tile % a.ncls, t2 = tile / a.ncls;
+    const unsigned m0 = (unsigned)(t2 / a.ntn) * BM;
+    const int n0 = (t2 % a.ntn) * BN;
+    const int dy0c = a.c_dy0[cls], dx0c = a.c_dx0[cls];
     const unsigned Mu = (unsigned)a.M, Wo = (unsigned)a.Wo, Ho = (unsigned)a.Ho;
     {
       unsigned m = m0 + srow;
@@ -116,8 +124,8 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         if (m < Mu) {
-          iy0[i] = (int)oy * a.in_stride + a.dy0;
-          ix0[i] = (int)ox * a.in_stride + a.dx0;
+          iy0[i] = (int)oy * a.in_stride + dy0c;
+          ix0[i] = (int)ox * a.in_stride + dx0c;
           // element offset of tap (0, 0), channel chunk_l * 8 of this row's pixel: a K step adds a UNIFORM term to it
           xo[i] = (long long)b * a.Hi * a.Wi * a.Cin + ((long long)iy0[i] * a.Wi + ix0[i]) * a.Cin + chunk_l * 8;
         } else {
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
       }
     }
 #pragma unroll
-    for (int i = 0; i < NB; ++i) wrow[i] = a.Wp + (long long)(n0 + srow + RSTEP * i) * a.K + chunk_l * 8;
+    for (int i = 0; i < NB; ++i) wrow[i] = a.c_wp[cls] + (long long)(n0 + srow + RSTEP * i) * a.K + chunk_l * 8;
     tap_a = 0; tap_b = 0; cstep = 0;
   };
   // One K step = NA + NB LDS-DMA pieces per wave.  piece(buf, j) requests piece j of the NEXT K step of the staged tile;
@@ -179,7 +187,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
   if (tile < ntiles) { set_tile(tile, 0); stage(0); }
   __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the first tile's first K step
   for (; tile < ntiles; tile += gridDim.x) {
-    const int m_tile = tile / a.ntn, n0 = (tile % a.ntn) * BN;
+    const int cls = tile % a.ncls, m_tile = (tile / a.ncls) / a.ntn, n0 = ((tile / a.ncls) % a.ntn) * BN;
     const bool has_next = tile + (int)gridDim.x < ntiles;
     f32x16 acc[MI][NI];
 #pragma unroll
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
         long long off = -1;
         if (m < Mu) {
           const unsigned q = m / Wo, ox = m - q * Wo, b = q / Ho, oy = q - b * Ho;
-          off = (((long long)b * a.Hy + (long long)oy * a.out_stride + a.out_oy) * a.Wy + (long long)ox * a.out_stride + a.out_ox) * a.N;
+          off = (((long long)b * a.Hy + (long long)oy * a.out_stride + a.c_oy[cls]) * a.Wy + (long long)ox * a.out_stride + a.c_ox[cls]) * a.N;
         }
         rowoff[r] = off;
       }
@@ -508,7 +516,7 @@ int launch(Geo g, hipStream_t s) {
   if (rc) return rc;
   g.ntm = (int)cy_ceil_div(g.M, BM);
   g.ntn = (int)cy_ceil_div(g.N, BN);
-  const long long ntiles = (long long)g.ntm * g.ntn;
+  const long long ntiles = (long long)g.ntm * g.ntn * g.ncls;
   const int resident = 256 * ((WM * WN == 8) ? 1 : 2);               // persistent blocks: what fits the chip at once
   const unsigned nblk = (unsigned)(ntiles < resident ? ntiles : resident);
   g.prof = nullptr;
@@ -556,8 +564,10 @@ extern "C" int cy_conv_bf16_pack_weights(const float* W, void* Wp, int Cout, int
   return 0;
 }
 
-extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* stream) {
-  CY_REQUIRE(a && a->X && a->Wp && a->Y, "cy_conv_gemm_bf16: null pointer");
+// ncls descriptors that differ only in Wp, dy0, dx0, out_oy, out_ox: the output-parity classes of a strided input gradient in ONE launch
+extern "C" int cy_conv_gemm_bf16_classes(const cy_conv_gemm_t* a, int ncls, int out_f32, void* stream) {
+  CY_REQUIRE(a && ncls >= 1 && ncls <= 4, "cy_conv_gemm_bf16_classes: 1 to 4 class descriptors");
+  CY_REQUIRE(a->X && a->Wp && a->Y, "cy_conv_gemm_bf16: null pointer");
   CY_REQUIRE(a->Cin % 64 == 0 && a->N % 64 == 0, "cy_conv_gemm_bf16: Cin=%d and N=%d must be multiples of 64", a->Cin, a->N);
   CY_REQUIRE(a->xs_c == 1 && a->xs_x == a->Cin && a->xs_y == (long long)a->Wi * a->Cin &&
              a->xs_b == (long long)a->Hi * a->Wi * a->Cin, "cy_conv_gemm_bf16: X must be plain NHWC");
@@ -571,8 +581,22 @@ extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* str
   g.out_stride = a->out_stride; g.out_oy = a->out_oy; g.out_ox = a->out_ox; g.act = a->act; g.act_slope = a->act_slope;
   CY_REQUIRE(a->act >= 0 && a->act <= 2 && (a->act != 2 || (a->act_slope >= 0.f && a->act_slope <= 1.f)),
              "cy_conv_gemm_bf16: act=%d / act_slope=%g (LeakyReLU slope must be in [0, 1])", a->act, (double)a->act_slope);
+  g.ncls = ncls;
+  for (int c = 0; c < 4; ++c) {
+    const cy_conv_gemm_t* q = a + (c < ncls ? c : 0);
+    if (c < ncls && c > 0) {
+      CY_REQUIRE(q->X == a->X && q->Y == a->Y && q->bias == a->bias && q->stats == a->stats && q->B == a->B && q->Hi == a->Hi &&
+                 q->Wi == a->Wi && q->Cin == a->Cin && q->Ho == a->Ho && q->Wo == a->Wo && q->N == a->N && q->TH == a->TH &&
+                 q->TW == a->TW && q->in_stride == a->in_stride && q->dstep == a->dstep && q->Hy == a->Hy && q->Wy == a->Wy &&
+                 q->out_stride == a->out_stride && q->act == a->act && q->bn_red == a->bn_red && q->bn_z == a->bn_z && q->Wp &&
+                 (((uintptr_t)q->Wp) & 15) == 0,
+                 "cy_conv_gemm_bf16_classes: class %d differs from class 0 in more than Wp / dy0 / dx0 / out_oy / out_ox", c);
+    }
+    g.c_dy0[c] = q->dy0; g.c_dx0[c] = q->dx0; g.c_oy[c] = q->out_oy; g.c_ox[c] = q->out_ox; g.c_wp[c] = (const u16*)q->Wp;
+  }
   g.M = (long long)a->B * a->Ho * a->Wo;
   CY_REQUIRE(g.M < (1ll << 31) - 512, "cy_conv_gemm_bf16: more than 2^31 output pixels");
+  CY_REQUIRE(g.M * ncls * ((a->N + 63) / 64) < (1ll << 31), "cy_conv_gemm_bf16: too many tiles");
   g.K = a->TH * a->TW * a->Cin;
   hipStream_t s = (hipStream_t)stream;
   int rc;
@@ -582,6 +606,10 @@ extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* str
   if (rc) return rc;
   CY_LAUNCH_CHECK("cy_conv_gemm_bf16");
   return 0;
+}
+
+extern "C" int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* stream) {
+  return cy_conv_gemm_bf16_classes(a, 1, out_f32, stream);
 }
 
 extern "C" int cy_cast_f32_bf16(const float* in, void* out, long long n, void* stream) {

@@ -734,6 +734,7 @@ def conv_forward_bf16(x, weight, bias, k, stride, pad, stats=None, tag='conv', l
     return z
 
 
+BF16_DGRAD_ONE_LAUNCH = True       # bf16 path: the output-parity classes of a strided input gradient in one launch (cy_conv_gemm_bf16_classes)
 FUSE_BN_BWD_REDUCE_BF16 = True     # bf16 path: the producer block's BatchNorm-backward sums out of the consumer's input-gradient epilogue
 
 
@@ -749,12 +750,14 @@ def conv_dgrad_bf16(dz, weight, in_shape, k, stride, pad, out_f32=False, tag='co
     _, Ho, Wo, Cout = dz.shape
     st = _stream()
     dx = torch.empty((B, Hi, Wi, Cin), dtype=torch.float32 if out_f32 else torch.bfloat16, device=dz.device)
-    wp = torch.empty((query('cy_conv_bf16_packed_elems', ((k + stride - 1) // stride) ** 2 * Cout, Cin),), dtype=torch.bfloat16,
-                     device=dz.device)
-    for c in dgrad_classes(Hi, Wi, k, stride, pad):
-        call('cy_conv_bf16_pack_weights', _ptr(weight), _ptr(wp), Cout, Cin, k, k, c['TH'], c['TW'], c['kh0'], c['kw0'],
+    classes = dgrad_classes(Hi, Wi, k, stride, pad)
+    nel = query('cy_conv_bf16_packed_elems', ((k + stride - 1) // stride) ** 2 * Cout, Cin)
+    wp = torch.empty((len(classes), nel), dtype=torch.bfloat16, device=dz.device)
+    descs = (ConvGemm * len(classes))()
+    for i, c in enumerate(classes):
+        call('cy_conv_bf16_pack_weights', _ptr(weight), _ptr(wp[i]), Cout, Cin, k, k, c['TH'], c['TW'], c['kh0'], c['kw0'],
              c['kstep'], 1, st)
-        a = ConvGemm(X=dz.data_ptr(), Wp=wp.data_ptr(), Y=dx.data_ptr(), bias=None, stats=None,
+        a = ConvGemm(X=dz.data_ptr(), Wp=wp[i].data_ptr(), Y=dx.data_ptr(), bias=None, stats=None,
                      xs_b=Ho * Wo * Cout, xs_y=Wo * Cout, xs_x=Cout, xs_c=1, B=B, Hi=Ho, Wi=Wo, Cin=Cout,
                      Ho=c['Ho'], Wo=c['Wo'], N=Cin, TH=c['TH'], TW=c['TW'], in_stride=1, dy0=c['dy0'], dx0=c['dx0'],
                      dstep=c['dstep'], Hy=Hi, Wy=Wi, out_stride=c['out_stride'], out_oy=c['out_oy'], out_ox=c['out_ox'], act=0)
@@ -762,8 +765,18 @@ def conv_dgrad_bf16(dz, weight, in_shape, k, stride, pad, out_f32=False, tag='co
             bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
             a.bn_z, a.bn_scale, a.bn_shift = _bf(bz, 'producer z').data_ptr(), bsc.data_ptr(), bsh.data_ptr()
             a.bn_mean, a.bn_invstd, a.bn_red, a.bn_slope = bmu.data_ptr(), bis.data_ptr(), bred.data_ptr(), float(bsl)
+        descs[i] = a
+    same = all((c['TH'], c['TW'], c['Ho'], c['Wo'], c['dstep'], c['out_stride']) ==
+               (classes[0]['TH'], classes[0]['TW'], classes[0]['Ho'], classes[0]['Wo'], classes[0]['dstep'], classes[0]['out_stride'])
+               for c in classes)
+    if BF16_DGRAD_ONE_LAUNCH and 1 < len(classes) <= 4 and same:
+        # the parity classes of a strided layer in ONE launch (even sizes: all classes have the same grid and taps)
         with timer.range('conv_bf16_dgrad/' + tag):
-            call('cy_conv_gemm_bf16', C.byref(a), 1 if out_f32 else 0, st)
+            call('cy_conv_gemm_bf16_classes', descs, len(classes), 1 if out_f32 else 0, st)
+    else:
+        for i in range(len(classes)):
+            with timer.range('conv_bf16_dgrad/' + tag):
+                call('cy_conv_gemm_bf16', C.byref(descs[i]), 1 if out_f32 else 0, st)
     return dx
 
 

@@ -261,6 +261,10 @@ int cy_conv_bf16_pack_weights(const float* W, void* Wp, int Cout, int Cin, int K
                               int kstep, int transpose, void* stream);
 /* forward / per-parity-class input gradient; X, Wp bf16; Y bf16, or fp32 when out_f32 (the consumer is an fp32 kernel) */
 int cy_conv_gemm_bf16(const cy_conv_gemm_t* a, int out_f32, void* stream);
+/* a[0 .. ncls-1] (ncls <= 4): descriptors that differ only in Wp, dy0, dx0, out_oy, out_ox -- the output-parity classes of a strided
+ * input gradient (models.py:352-363 backward) -- in ONE launch: the classes of a pixel tile run on neighbouring blocks at the same
+ * time, so X is fetched from HBM once instead of once per class. */
+int cy_conv_gemm_bf16_classes(const cy_conv_gemm_t* a, int ncls, int out_f32, void* stream);
 /* weight gradient dW[Cout][Cin][KH][KW] (fp32) of a pad-1 3x3/stride-1 or 4x4/stride-2 layer from bf16 X and dZ;
  * ws: cy_conv_wgrad_bf16_ws_floats() floats of per-split partial sums, added in a fixed order (-1: unsupported shape) */
 long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride);
