@@ -85,7 +85,7 @@ struct Geo {
 //    16-byte chunk c of row r lives at chunk c ^ ((r >> 1) & 7) -- applied on the DMA's per-lane SOURCE address and on
 //    the fragment reads -- so that the 16 lanes of a ds_read_b128 group fall on 16 different bank groups.
 //  * padding pixels and rows past M read 16 zero bytes (conv_bf16_zero16): the DMA is unconditional.
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false, bool TAPIN = false>
 __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf16_kernel(Geo a) {
   static_assert(!(BNF && OUT_F32), "the fused BatchNorm-backward sums are built for the bf16 output");
   constexpr int NT = 64 * WM * WN;
@@ -162,7 +162,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
                                        (__attribute__((address_space(3))) void*)(Ab + A_BYTES + (j - NA) * RSTEP * ROWB), 16, 0, 0);
     }
   };
-  auto step_done = [&]() { if (++cstep == cpt) { cstep = 0; if (++tap_b == a.TW) { tap_b = 0; ++tap_a; } } };
+  // K order: the TAPS are the inner loop, the 64-channel chunk the outer one.  A K step reads one 128-byte line per pixel row of the tile;
+  // with the channel chunks inside a tap (the first version) a line was touched again only cpt steps later, for the next tap -- 256 KB of
+  // other lines per block in between, 8 MB per XCD against 4 MB of L2: conv_2's input gradient at 608^2 fetched 56 GB for 6 GB of dz
+  // (FETCH_SIZE; 6.4 TB/s: the launch was bound by those re-reads).  Taps inside: the next TH x TW steps re-read the same lines shifted.
+  // (only where it matters -- cpt x BM x 128 B x 32 blocks beyond the L2, Geo.tap_inner set by the launcher: conv_2's forward with 2 chunks
+  // per tap and 256-row tiles was 2 % faster the old way)
+  // (a TEMPLATE parameter: as a run-time flag the branch in this cursor doubled every launch's time)
+  auto step_done = [&]() {
+    if constexpr (TAPIN) { if (++tap_b == a.TW) { tap_b = 0; if (++tap_a == a.TH) { tap_a = 0; ++cstep; } } }
+    else { if (++cstep == cpt) { cstep = 0; if (++tap_b == a.TW) { tap_b = 0; ++tap_a; } } }
+  };
   auto stage = [&](int buf) {                       // a whole K step at once (prologue)
 #pragma unroll
     for (int j = 0; j < NA + NB; ++j) piece(buf, j);
@@ -509,13 +519,18 @@ __global__ void cast_kernel_b2f(const u16* __restrict__ in, float* __restrict__ 
   }
 }
 
-template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false>
+template <int BM, int BN, int WM, int WN, bool OUT_F32, bool BNF = false, bool TAPIN = false>
 int launch(Geo g, hipStream_t s) {
+  if constexpr (!TAPIN) {
+    // taps inside a channel chunk where a tile's lines would not survive in L2 between two taps (see step_done)
+    if ((g.Cin / BK) * BM > 768 && g.TH * g.TW > 1) return launch<BM, BN, WM, WN, OUT_F32, BNF, true>(g, s);
+  }
   const size_t lds = (size_t)2 * (BM + BN) * ROWB;
-  int rc = cy_allow_lds(conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF>, lds);
+  int rc = cy_allow_lds(conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF, TAPIN>, lds);
   if (rc) return rc;
   g.ntm = (int)cy_ceil_div(g.M, BM);
   g.ntn = (int)cy_ceil_div(g.N, BN);
+
   const long long ntiles = (long long)g.ntm * g.ntn * g.ncls;
   const int resident = 256 * ((WM * WN == 8) ? 1 : 2);               // persistent blocks: what fits the chip at once
   const unsigned nblk = (unsigned)(ntiles < resident ? ntiles : resident);
@@ -525,7 +540,7 @@ int launch(Geo g, hipStream_t s) {
     (void)hipMalloc(&g.prof, nblk * 64);
     (void)hipMemsetAsync(g.prof, 0, nblk * 64, s);
   }
-  conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF><<<nblk, 64 * WM * WN, lds, s>>>(g);
+  conv_bf16_kernel<BM, BN, WM, WN, OUT_F32, BNF, TAPIN><<<nblk, 64 * WM * WN, lds, s>>>(g);
   if (prof_on) {
     (void)hipStreamSynchronize(s);
     long long* h = (long long*)malloc(nblk * 64);

@@ -119,3 +119,27 @@ if what in ('routing', 'all'):
     v3 = ops.routing(feat, W3, 3, g, B)
     gv3 = torch.randn_like(v3)
     timeit('routing fwd+bwd DarkCapsuleNet3 head', lambda: torch.autograd.grad(ops.routing(feat, W3, 3, g, B), (feat, W3), gv3))
+if what == 'bf16':
+    # the bf16 path's conv_2 / conv_3 launches at the 608 x 608 shape of BASELINE configs[4] (not part of `all`: 19 GB of operands)
+    H = int(os.environ.get('CY_BF16_H', '608'))
+    BF = torch.bfloat16
+    x = torch.randn(B, H, H, 128, device=dev).to(BF)
+    w = torch.randn(256, 128, 3, 3, device=dev) * 0.03
+    b = torch.zeros(256, device=dev)
+    dz = torch.randn(B, H, H, 256, device=dev).to(BF)
+    fl = 2.0 * B * H * H * 256 * 1152
+    stats = torch.zeros(ops.STATS_COPIES, 256, 2, dtype=torch.float64, device=dev)
+    timeit('bf16 conv2 fwd (+stats)', lambda: ops.conv_forward_bf16(x, w, b, 3, 1, 1, stats), fl)
+    timeit('bf16 conv2 dgrad (fp32 out)', lambda: ops.conv_dgrad_bf16(dz, w, (B, H, H, 128), 3, 1, 1, True), fl)
+    timeit('bf16 conv2 wgrad', lambda: ops.conv_wgrad_bf16(x, dz, 3, 1, 1), fl)
+    del x
+    w3 = torch.randn(64, 256, 4, 4, device=dev) * 0.03
+    dz3 = torch.randn(B, H // 2, H // 2, 64, device=dev).to(BF)
+    z2 = dz                                       # (any bf16 tensor of conv_2's output shape plays z)
+    sc, sh = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+    mu, isd = torch.randn(256, device=dev) * 0.1, torch.rand(256, device=dev) + 0.5
+    red = torch.zeros(ops.STATS_COPIES, 256, 2, dtype=torch.float64, device=dev)
+    fl3 = 2.0 * B * (H // 2) ** 2 * 64 * 4096
+    timeit('bf16 conv3 dgrad, 4 classes in one launch + bn sums',
+           lambda: ops.conv_dgrad_bf16(dz3, w3, (B, H, H, 256), 4, 2, 1, False, 'c', (z2, sc, sh, mu, isd, 0.1, red)), fl3)
+    timeit('bf16 conv3 dgrad, one launch', lambda: ops.conv_dgrad_bf16(dz3, w3, (B, H, H, 256), 4, 2, 1), fl3)
