@@ -193,7 +193,12 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
     for (int i = 0; i < phase * (KT + 6); ++i) __builtin_amdgcn_s_sleep(8);
   }
   int cur = 0, slot = 0;
+  // Consecutive tiles are consecutive pixel segments: the rows a 3 x 3 tap reads above and below a tile are the rows of the next
+  // one or two tiles.  Blocks go to the XCDs round-robin, so each XCD takes a CONTIGUOUS range of tiles per round (the Winograd
+  // kernels' remap): the neighbours' lines are then in the same L2 (conv_2's input gradient still fetched 21.7 GB for 6 GB of dz:
+  // every line once per tap row).
   int tile = blockIdx.x;
+  if ((gridDim.x & 7u) == 0) tile = (int)((blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3));
   if (tile < ntiles) { set_tile(tile, 0); stage(0); }
   __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): the first tile's first K step
   for (; tile < ntiles; tile += gridDim.x) {
