@@ -117,6 +117,18 @@ def perturb_one_ulp(x):
     return out.astype(np.float32).reshape(x.shape)
 
 
+def perturb_ulps(x, seed, ulps=1):
+    """Every element of a float32 array moved by exactly ``ulps`` ulps, up or down by a coin flip seeded with ``seed`` (the members of
+    the loss-curve ensembles: tests/golden/curves_ens.npz)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    up = np.random.default_rng(seed).integers(0, 2, x.size).astype(bool).reshape(x.shape)
+    hi, lo = x.copy(), x.copy()
+    for _ in range(int(ulps)):
+        hi = np.nextafter(hi, np.float32(np.inf))
+        lo = np.nextafter(lo, np.float32(-np.inf))
+    return np.where(up, hi, lo).astype(np.float32)
+
+
 _DARKNET_COUT = [32, 64, 128, 64, 128, 256, 128, 256, 512, 256, 512, 256, 512, 1024, 512, 1024, 512, 1024]
 _DARKNET_K = [3, 3, 3, 1, 3, 3, 1, 3, 3, 1, 3, 1, 3, 3, 1, 3, 1, 3]
 

@@ -77,9 +77,14 @@ def test_c2_darknet_d_416_batch16():
     assert rel_l2(ho, oo) < 2e-4
     assert abs(hl.item() - ol.item()) <= 1e-4 * abs(ol.item())
     og = dict((n, q.grad) for n, q in o.named_parameters())
-    tail = [n for n, q in h.named_parameters() if q.grad is not None][-6:]     # the head and the block below it
-    for n in tail:
-        assert rel_l2(dict(h.named_parameters())[n].grad, og[n]) < 2e-2, n
+    # every parameter within 2e-2 (measured round 4: 2e-6 at the head rising to 6.7e-3 at the first block -- 18 LeakyReLU layers of
+    # kink flips between fp32 evaluation orders: the reference's own fp32 path is 6e-4 .. 1.5e-2 from its fp64 run on this net, DESIGN
+    # section 2; the layer-by-layer fp64 yardstick is test_gpu_models.py's models64 comparison)
+    names = [n for n, q in h.named_parameters() if q.grad is not None]
+    worst = dict((n, rel_l2(dict(h.named_parameters())[n].grad, og[n])) for n in names)
+    print('DarkNet gradients at 416 x 416 against the oracle (relative L2): ' + ', '.join('%s %.1e' % (n, worst[n]) for n in names))
+    for n in names:
+        assert worst[n] < 2e-2, (n, worst[n])
     x, y = T(synth_images(16, H, seed=53)).cuda(), T(synth_gtsdb_labels(16, g, 0, seed=54)).cuda()
     _step_properties(h, lambda net: loss_fns.dark_loss(net(x), y, p), lambda net: [q for q in net.parameters() if q.requires_grad])
 
@@ -104,13 +109,25 @@ def test_c3_darkcapsule_416_batch32():
     assert rel_l2(ho, oo) < 2e-4
     assert abs(hl.item() - ol.item()) <= 1e-4 * abs(ol.item())
     og = dict((n, q.grad) for n, q in o.named_parameters())
+    # EVERY parameter with a gradient, no filter: conv_1 / bn_1 = patch-moment statistics + the one-pass
+    # backward; conv_2 / bn_2 = F(4x4,3x3) / F(3x3,4x4) with the fused BatchNorm backward; conv_3 / bn_3, conv_4 / bn_4 = F(4x4,2x2)
+    # forward and input gradient with the producer's BatchNorm sums, at map sizes (208^2, 104^2) that no other test reaches.
+    # The one deliberate difference: a conv bias in front of BatchNorm gets gradient exactly 0 here; the
+    # reference's value is the rounding noise of a sum that is analytically 0 (checked: tiny against the layer's weight gradient).
+    worst = {}
     for n, q in h.named_parameters():
         if q.grad is None:
             assert og[n] is None, n
-        elif ('route_weights' in n or 'conv_5.weight' in n or 'bn_5' in n or 'conv_2.weight' in n or 'bn_2' in n
-              or 'conv_1.weight' in n or 'bn_1' in n):     # (conv_1 / bn_1: patch-moment statistics + the one-pass backward)
-            # (conv_2 / bn_2: the weight gradient with the fused BatchNorm backward, csrc/winograd.hip, at the full map size)
-            assert rel_l2(q.grad, og[n]) < 2e-2, n
+        elif n.startswith('conv.conv_') and n.endswith('.bias'):
+            assert float(q.grad.abs().max()) == 0.0, n
+            wn = n[:-len('bias')] + 'weight'
+            assert float(og[n].abs().max()) <= 1e-3 * float(og[wn].abs().max()), n
+        else:
+            worst[n] = rel_l2(q.grad, og[n])
+    print('gradients at 416 x 416 against the oracle (relative L2): ' + ', '.join('%s %.1e' % kv for kv in sorted(worst.items())))
+    assert set(worst) >= set('conv.%s_%d.weight' % (k, i) for k in ('conv', 'bn') for i in range(1, 6)), sorted(worst)
+    for n, e in worst.items():      # measured round 4: 1.5e-5 (routing weights) .. 2.5e-3 (bn_2.bias); 5.3e-4 / 3.3e-4 on conv_3 / conv_4
+        assert e < 1e-2, (n, e)
     x, y = T(synth_images(32, H, seed=63)).cuda(), T(synth_gtsdb_labels(32, g, 43, seed=64)).cuda()
     _step_properties(h, lambda net: loss_fns.darkcapsule_loss(net(x), y, p),
                      lambda net: [q for q in net.parameters() if q.requires_grad])
@@ -146,3 +163,41 @@ def test_c5_darkcapsule_608_r5_bf16():
     x, y = T(synth_images(8, H, seed=73)).cuda(), T(synth_gtsdb_labels(8, g, 43, seed=74)).cuda()
     _step_properties(h, lambda net: loss_fns.darkcapsule_loss(net(x), y, p),
                      lambda net: [q for q in net.parameters() if q.requires_grad])
+
+
+def test_c1_capsule_32_batch32():
+    """configs[0] at its full shape on the GPU: experiments/capsule, GTSRB 32 x 32, 43 classes, 3 routing iterations, BATCH 32 with the
+    reconstruction decoder (the head runs R = 32, N = 1296, C = 43, 8 -> 16: the phased few-rows routing plan).  The oracle runs a
+    batch of 32 of this small model in seconds, so the comparison is at the full batch: scores, reconstruction, loss and the
+    gradient of every parameter; then the full-batch step properties."""
+    from capsyolo_amd import loss_fns, models
+    from oracle import loss_fns as OL
+    from oracle import models as OM
+    p = make_params(model='capsule', recon=True, device='cuda', batch_size=32)
+    po = make_params(model='capsule', recon=True, batch_size=32)
+    o, h = _seeded_pair(lambda: OM.CapsuleNet(po), lambda: models.CapsuleNet(p))
+    x, y = T(synth_images(32, 32, seed=81)), T(np.random.default_rng(82).integers(0, 43, 32).astype(np.int64))
+    os_, orec = o(x, y, True)
+    ol = OL.capsule_loss(os_, y, po, x, orec)
+    ol.backward()
+    hs, hrec = h(x.cuda(), y.cuda(), True)
+    hl = loss_fns.capsule_loss(hs, y.cuda(), p, x.cuda(), hrec)
+    hl.backward()
+    assert tuple(hs.shape) == (32, 43) and tuple(hrec.shape) == tuple(orec.shape)
+    assert rel_l2(hs, os_) < 2e-4 and rel_l2(hrec, orec) < 2e-4
+    assert abs(hl.item() - ol.item()) <= 1e-4 * abs(ol.item())
+    og = dict((n, q.grad) for n, q in o.named_parameters())
+    worst = {}
+    for n, q in h.named_parameters():
+        assert (q.grad is None) == (og[n] is None), n
+        if q.grad is not None:
+            worst[n] = rel_l2(q.grad, og[n])
+    print('CapsuleNet batch 32 gradients against the oracle (relative L2): ' + ', '.join('%s %.1e' % kv for kv in sorted(worst.items())))
+    for n, e in worst.items():      # measured round 4: 8e-8 .. 2.7e-6 (no BatchNorm, the seeded default initialisation)
+        assert e < 1e-4, (n, e)
+    xc, yc = x.cuda(), y.cuda()
+
+    def fwd(net):
+        s, rec = net(xc, yc, True)
+        return loss_fns.capsule_loss(s, yc, p, xc, rec)
+    _step_properties(h, fwd, lambda net: [q for q in net.parameters() if q.requires_grad])
