@@ -420,3 +420,64 @@ def test_darkcapsule2_net_golden():
         elif not ('.conv_' in name and name.endswith('bias')):
             ref = g[key]
             close(grad_digest(q.grad), ref, 5e-3, 5e-3 * max(1e-6, float(np.abs(ref[2:]).max())))
+
+
+# ----------------------------------------------------------------------------- round-4 fixture: the loss-curve ensembles
+def test_curve_ensembles_are_consistent_and_the_envelope_can_fail():
+    """tests/golden/curves_ens.npz (make_golden.py curves_ens): per recipe the reference's unperturbed curve, its fp64 run and 8 + 8
+    runs with every input element moved by 1 / 16 ulps.  Pinned here: the di96 / di256 base curves ARE those of curves_init.npz; the
+    well-conditioned recipe (dw64) keeps its one-ulp band under 0.5 % of the range on all 20 steps (in fact 2e-5)
+    and falls monotonically; the envelope holds (nearly all of) its own members and rejects an offset of 3e-4 of the range on one
+    step or a relative 3e-4 on the first step; no run of the reference itself fails its leave-one-out envelope."""
+    from helpers import curve_envelope, curve_in_envelope
+    g, gi = load_golden('curves_ens'), load_golden('curves_init')
+    for tag in ('di96', 'di256'):
+        assert np.array_equal(g[tag + '_curve'], gi[tag + '_curve'])
+        np.testing.assert_array_equal(g[tag + '_init_digest'], gi[tag + '_init_digest'])
+    for tag in ('di96', 'di256', 'dw64'):
+        assert g[tag + '_ens1'].shape == (8, 20) and g[tag + '_ens16'].shape == (8, 20)
+        # leave-one-out: no run of the reference itself (the 17 members, and its fp64 run against all 17) leaves the envelope built
+        # from the others -- the property that makes a red GPU test mean something (a per-step 3 sigma_k bound rejects 6 of di96's 18)
+        full = curve_envelope(g, tag)
+        for m in range(17):
+            dev, ok = curve_in_envelope(full['members'][m], curve_envelope(g, tag, leave_out=m))
+            assert ok.all(), (tag, m, np.nonzero(~ok)[0].tolist())
+        assert curve_in_envelope(full['curve64'], full)[1].all(), tag
+        assert int(full['strict'].sum()) == {'di96': 4, 'di256': 3, 'dw64': 20}[tag] and full['strict'][:3].all()
+        three_sigma_rejects = sum(1 for m in range(17) for e in [curve_envelope(g, tag, leave_out=m)]
+                                  if not (np.abs(full['members'][m] - e['mean']) <= np.maximum(e['floor'], 3 * e['sigma'])).all())
+        assert three_sigma_rejects >= (4 if tag == 'di96' else 0)                # (what the plain rule does to the reference's own runs)
+        assert (full['bound'][1:3] <= 1e-2 * full['span']).all()                # the early steps are tight on every recipe
+    env = curve_envelope(g, 'dw64', floor_frac=1e-4)
+    assert (env['one_ulp_band'] <= 5e-3 * env['span']).all() and env['one_ulp_band'].max() <= 3e-5 * env['span']
+    assert (np.diff(env['base']) < 0).all()
+    assert (3 * env['sigma'] <= env['floor'])[1:].all()                          # dw64: the floor is the bound on every step
+    assert curve_in_envelope(env['curve64'], env)[1].all()                       # the reference in double lies inside
+    bad = env['base'].copy()
+    bad[7] += 3e-4 * env['span']
+    assert not curve_in_envelope(bad, env)[1][7] and curve_in_envelope(bad, env)[1].sum() == 19
+    bad = env['base'].copy()
+    bad[0] *= 1 + 3e-4
+    assert not curve_in_envelope(bad, env)[1][0]
+
+
+def test_oracle_curve_inside_the_ensemble_envelope():
+    """The oracle's own 20-step curve of the 96 x 96 default-initialisation recipe (a different host / thread count than the one
+    that wrote the fixture is one more equally valid fp32 evaluation order) lies inside the per-step envelope on its strict steps (0 .. 3) and passes the verdict the GPU tests use (helpers.envelope_verdict)."""
+    from helpers import curve_envelope, envelope_verdict
+    g = load_golden('curves_ens')
+    H, gg, B, seed, init_seed = (int(v) for v in g['di96_cfg'])
+    p = make_params(model='darkcapsule', n_grid=gg, darknet_input=H, recon=False)
+    x, y = T(synth_images(B, H, seed=seed)), T(synth_gtsdb_labels(B, gg, 43, seed=seed + 1))
+    torch.manual_seed(init_seed)
+    net = OM.DarkCapsuleNet(p).train()
+    opt = torch.optim.Adam([q for q in net.parameters() if q.requires_grad], lr=1e-3)
+    curve = []
+    for _ in range(20):
+        loss = OL.darkcapsule_loss(net(x), y, p)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        curve.append(loss.item())
+    v = envelope_verdict(curve, curve_envelope(g, 'di96'))
+    assert v['ok'] and v['strict_ok'], (v['steps_within_envelope'], v['dev'].tolist())
