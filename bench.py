@@ -319,7 +319,7 @@ _KIND_PEAKS = {   # timer key prefix -> (issued / direct-convolution FLOPs, MFMA
 
 
 def secondary(dev, steps=5):
-    """BASELINE configs[1] and configs[4] (one GPU's share) on the same driver-timed line, bounded: 5 timed steps each after
+    """BASELINE configs[1], configs[4] (one GPU's share) and configs[0] (on the GPU) on the same driver-timed line, bounded: 5 timed steps each after
     3 / 2 warm-up steps with the batch resident in HBM, then 3 more steps under the per-launch HIP-event timer for the
     dominant conv kernel's fraction of its MFMA peak (the brackets slow a 235-launch step by ~20 %: they are NOT in `value`)."""
     import torch
@@ -381,6 +381,36 @@ def secondary(dev, steps=5):
         'value': round(B / dt, 2), 'unit': 'images/s', 'ms_per_step': round(1e3 * dt, 3), 'steps': steps, 'warmup': 2,
         'dtype': 'bf16', 'final_loss': round(final, 6), 'roofline': _dominant(ops, flops, 3, _KIND_PEAKS),
         'train_gflop_per_image': round(3 * sum(flops.values()) / B / 1e9, 2)}
+    del net, opt, x, y
+    torch.cuda.empty_cache()
+    # --- configs[0] on the GPU: experiments/capsule, GTSRB-shaped 32x32, 43 classes, 3 routing iterations, batch 32, reconstruction on
+    B = 32
+    p = types.SimpleNamespace(n_classes=43, dropout=0.0, recon=True, recon_coef=5e-4, device='cuda', model='capsule')
+    torch.manual_seed(0)
+    net = models.CapsuleNet(p).to(dev).train()
+    opt = optim.Adam([q for q in net.parameters() if q.requires_grad], lr=1e-3)
+    x = torch.from_numpy(synth.images(B, 32)).permute(0, 3, 1, 2).contiguous().to(dev)
+    y = torch.from_numpy(synth.gtsrb_labels(B, 43)).to(dev)
+
+    def step0():
+        scores, recon = net(x, y, True)
+        loss = loss_fns.capsule_loss(scores, y, p, x, recon)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        return loss
+    dt, final = _timed_steps(step0, 5, 4 * steps)
+    ops.timer.reset()
+    ops.timer.enabled = True
+    _timed_steps(step0, 0, 3)
+    ops.timer.enabled = False
+    kt = ops.timer.summary()
+    out['capsule_32_b32_f32'] = {
+        'config': {'workload': 'experiments/capsule GTSRB-shaped 32x32, 43 classes, 3 routing iters, batch 32, recon on, fp32 '
+                               '(BASELINE configs[0] on the GPU)'},
+        'value': round(B / dt, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dt, 3), 'steps': 4 * steps, 'warmup': 5,
+        'dtype': 'f32', 'final_loss': round(final, 6),
+        'kernel_ms_per_step': dict((k, round(ms * cnt / 3, 4)) for k, (cnt, ms) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8])}
     del net, opt, x, y
     torch.cuda.empty_cache()
     return out

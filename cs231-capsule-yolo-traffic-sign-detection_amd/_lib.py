@@ -22,7 +22,8 @@ class ConvGemm(C.Structure):
                 ('Hy', C.c_int), ('Wy', C.c_int), ('out_stride', C.c_int), ('out_oy', C.c_int), ('out_ox', C.c_int),
                 ('act', C.c_int),
                 ('bn_z', C.c_void_p), ('bn_scale', C.c_void_p), ('bn_shift', C.c_void_p), ('bn_mean', C.c_void_p),
-                ('bn_invstd', C.c_void_p), ('bn_red', C.c_void_p), ('bn_slope', C.c_float), ('act_slope', C.c_float)]
+                ('bn_invstd', C.c_void_p), ('bn_red', C.c_void_p), ('bn_slope', C.c_float), ('act_slope', C.c_float),
+                ('ws', C.c_void_p), ('ws_floats', _ll)]
 
 
 class ConvWgrad(C.Structure):
@@ -152,11 +153,12 @@ _RET = {
     'cy_wino2_wgrad_ws_floats': (_L, [_I, _I, _I]),
     'cy_wino_wgrad_ws_floats': (_L, [_I, _I, _I]),
     'cy_conv_wgrad_ws_floats': (_L, [C.POINTER(ConvWgrad)]),
+    'cy_conv_gemm_ws_floats': (_L, [C.POINTER(ConvGemm)]),
     'cy_routing_bwd_ws_floats': (_L, [C.POINTER(RoutingBwd)]),
     'cy_routing_fwd_ws_floats': (_L, [C.POINTER(RoutingFwd)]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
-ABI_VERSION = 3     # what the signatures above were written against (include/capsyolo_hip.h, csrc/error.cpp)
+ABI_VERSION = 4     # what the signatures above were written against (include/capsyolo_hip.h, csrc/error.cpp)
 
 _lib = None
 

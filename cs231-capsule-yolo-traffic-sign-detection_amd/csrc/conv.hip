@@ -23,6 +23,11 @@ struct GemmGeom {
   int Np, K, KT;
   long long M;
   int corder;          // 1: K tiles run taps fastest, channel blocks slowest (input pixels are re-read while they are in L2)
+  // split of the reduction (round 4): a layer whose output grid is far below the 256 CUs (CapsuleNet's primary-capsule convolution:
+  // 42 blocks x 648 K tiles) runs S blocks per output tile on kt_per K tiles each; every block leaves its RAW partial sums in its
+  // slab ws[split][M][Np] and conv_gemm_splitk_finish adds the slabs in split order (deterministic), then bias / activation.
+  int S, kt_per, tiles;
+  float* ws;
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
@@ -48,8 +53,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
   const int li = lane & 31, lh = lane >> 5;
 
   const int ntiles_n = g.Np / BN;
-  const long long mt = blockIdx.x / ntiles_n;
-  const int nt = blockIdx.x % ntiles_n;
+  const int sp = g.S > 1 ? (int)(blockIdx.x / (unsigned)g.tiles) : 0;      // this block's share of the reduction
+  const unsigned tile_id = g.S > 1 ? blockIdx.x % (unsigned)g.tiles : blockIdx.x;
+  const int kb = sp * g.kt_per, ke = (kb + g.kt_per < g.KT) ? kb + g.kt_per : g.KT;
+  const long long mt = tile_id / ntiles_n;
+  const int nt = tile_id % ntiles_n;
   const long long m0 = mt * BM;
   const int n0 = nt * BN;
   const int HoWo = a.Ho * a.Wo;
@@ -107,6 +115,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
   const float* wsrc = a.Wp + ((long long)b_kq0 * g.Np + n0 + b_n) * 4;
   constexpr int B_KQ_STEP = 256 / BN;     // kq advance per q
   const long long w_tile = (long long)8 * g.Np * 4;
+  if (kb > 0) {                            // a later share of the reduction: the cursors start at K tile kb
+    if (VEC) {
+      const int ntap = a.TH * a.TW, cblk = a.Cin >> 5;
+      const int tap = g.corder ? kb % ntap : kb / cblk;
+      c0 = 32 * (g.corder ? kb / ntap : kb % cblk);
+      tap_a = tap / a.TW; tap_b = tap - tap_a * a.TW;
+    }
+    if (!(VEC && g.corder)) wsrc += w_tile * kb;
+  }
 
 #define CY_LOAD_A_VEC(R, Q)                                                                        \
   {                                                                                                \
@@ -139,10 +156,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
 
   __syncthreads();                         // ktab / rowoff visible
 
-  // kt = -1 is the prologue (load + store tile 0, nothing to compute)
-  for (int kt = -1; kt < g.KT; ++kt) {
+  // kt = kb - 1 is the prologue (load + store the first tile, nothing to compute)
+  for (int kt = kb - 1; kt < ke; ++kt) {
     const int ktn = kt + 1;
-    const bool more = ktn < g.KT;
+    const bool more = ktn < ke;
     if (more) {
       // B first: hipcc guards the B destination registers with a conservative vmcnt wait, which is free
       // while nothing is in flight and would otherwise drain the A loads issued just before it
@@ -165,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
         CY_LOAD_A_SCALAR(ra0, 0) CY_LOAD_A_SCALAR(ra1, 1) CY_LOAD_A_SCALAR(ra2, 2) CY_LOAD_A_SCALAR(ra3, 3)
       }
     }
-    if (kt >= 0) {
+    if (kt >= kb) {
       const int cur = kt & 1;
       const float* Ab = As + cur * A_BUF + (wave_m * 64 + li) * 4;
       const float* Bb = Bs + cur * B_BUF + (wave_n * 32 * NTW + li) * 4;
@@ -230,6 +247,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
   // 64 (32) four-byte ones (conv_1, whose launch is nothing but its 2.8 GB of output, ran at 1.3 TB/s before).
   constexpr int WC = 32 * NTW;             // columns of the wave tile
   float* ow = smem + wave * (64 * WC);     // [64 rows][WC]; all waves are past the K loop's last barrier
+  if (g.S > 1) {
+    // split reduction: the raw partial sums of this share go to its slab (the padded columns too: Np floats per row, 16-byte stores)
+#pragma unroll
+    for (int ni = 0; ni < NTW; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ow[(mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * WC + ni * 32 + li] = acc[mi][ni][r];
+    constexpr int LPR = WC / 4, RPI = 64 / LPR;
+    const int c4 = lane % LPR, rsub = lane / LPR;
+    float* slab = g.ws + (long long)sp * g.M * g.Np + n0 + wave_n * WC + c4 * 4;
+#pragma unroll
+    for (int it = 0; it < 64 / RPI; ++it) {
+      const int row_l = it * RPI + rsub;
+      const long long m = m0 + wave_m * 64 + row_l;
+      if (m < g.M) *(f32x4*)(slab + m * g.Np) = *(const f32x4*)(ow + row_l * WC + c4 * 4);
+    }
+    return;
+  }
   float ssum[NTW], ssq[NTW];
 #pragma unroll
   for (int ni = 0; ni < NTW; ++ni) {
@@ -339,6 +375,32 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(cy_conv_gemm_t a, Gem
       atomicAdd(st + 2 * (n0 + t), s);
       atomicAdd(st + 2 * (n0 + t) + 1, q);
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Split reduction, second launch: Y = act(sum over the S slabs (in split order: deterministic) + bias); one thread per (pixel, 4 channels).
+__global__ void conv_gemm_splitk_finish(cy_conv_gemm_t a, GemmGeom g) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = g.Np / 4;
+  if (idx >= g.M * nq) return;
+  const long long m = idx / nq;
+  const int n = (int)(idx - m * nq) * 4;
+  if (n >= a.N) return;
+  const float* p = g.ws + m * g.Np + n;
+  f32x4 v = *(const f32x4*)p;
+  for (int s_ = 1; s_ < g.S; ++s_) v += *(const f32x4*)(p + (long long)s_ * g.M * g.Np);
+  const unsigned pp = (unsigned)m, HoWo = (unsigned)(a.Ho * a.Wo);
+  const unsigned b = pp / HoWo, r = pp - b * HoWo;
+  const int oy = (int)(r / (unsigned)a.Wo), ox = (int)(r - (unsigned)oy * (unsigned)a.Wo);
+  float* y = a.Y + (((long long)b * a.Hy + (oy * a.out_stride + a.out_oy)) * a.Wy + (ox * a.out_stride + a.out_ox)) * a.N + n;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if (n + k >= a.N) break;
+    float x = v[k] + (a.bias != nullptr ? a.bias[n + k] : 0.f);
+    if (a.act == 1) x = fmaxf(x, 0.f);
+    else if (a.act == 2) x = fmaxf(x, x * a.act_slope);
+    y[k] = x;
   }
 }
 
@@ -635,9 +697,15 @@ __global__ void channel_sum_kernel(const float* __restrict__ dZ, float* __restri
 // Pixel splits of the weight-gradient reduction.  Blocks are long-running (thousands of MFMA stages) and only
 // 2 fit a CU (80 KiB of LDS each), so the grid is sized to fill whole rounds of the 512 resident slots: a grid
 // of 3.02 rounds costs 4.
-int pick_splits(int tiles, long long M) {
+int pick_splits(int tiles, long long M, long long slab_floats) {
   const long long capacity = 512;
-  long long cap = M / 1024;                 // keep >= 1024 pixels (32 stages) per split
+  // keep >= 1024 pixels (32 stages) per split where a split's slab is large (conv_2: 1.2 MB written and read back per split); a layer
+  // with a tiny gradient (CapsuleNet's decoder: K N = 288 .. 1152 floats) is a chain of load latencies, not of work: down to 128
+  // pixels per split (its 8192-pixel layer ran 8 blocks for 0.55 ms of a 2.8 ms step)
+  long long min_px = slab_floats / 64;
+  if (min_px < 128) min_px = 128;
+  if (min_px > 1024) min_px = 1024;
+  long long cap = M / min_px;
   if (cap < 1) cap = 1;
   long long best = 1;
   double best_util = 0.0;
@@ -666,7 +734,7 @@ WgradPlan plan_wgrad(const cy_conv_wgrad_t* a) {
   else { p.variant = 1; p.BMK = 128; p.BNN = 64; }
   p.ktiles = (K + p.BMK - 1) / p.BMK;
   p.ntiles = (a->N + p.BNN - 1) / p.BNN;
-  p.S = pick_splits(p.ktiles * p.ntiles, M);
+  p.S = pick_splits(p.ktiles * p.ntiles, M, (long long)K * a->N);
   long long pps = (M + p.S - 1) / p.S;
   pps = (pps + PT - 1) / PT * PT;
   p.pix_per_split = pps;
@@ -699,6 +767,52 @@ extern "C" int cy_conv_pack_weights(const float* W, float* Wp, int Cout, int Cin
   return 0;
 }
 
+namespace {
+// tile width and split of the reduction for one launch (shared by cy_conv_gemm and its workspace query)
+struct GemmPlan { int ntw, S, kt_per; long long tiles; };
+GemmPlan plan_gemm(const cy_conv_gemm_t* a, const GemmGeom& g) {
+  GemmPlan p;
+  p.ntw = (g.Np % 128 == 0) ? 2 : 1;
+  const long long mtiles = cy_ceil_div(g.M, BM);
+  // a grid far below the 256 CUs (CapsuleNet's primary-capsule convolution: 21 row tiles x 1 column tile of 128, 648 K
+  // steps each) gets 64-column tiles: twice the blocks
+  if (p.ntw == 2 && mtiles * (g.Np / 128) < 128) p.ntw = 1;
+  p.tiles = mtiles * (g.Np / (64 * p.ntw));
+  p.S = 1; p.kt_per = g.KT;
+  // ... and, still far below two blocks per CU with a long reduction, S blocks per tile on a share of the K tiles each (>= 8 per
+  // share; not with the fused statistics epilogues, which need the finished sums)
+  int dev = 0, ncu = 256;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0)
+    ncu = 256;
+  if (a->stats == nullptr && a->bn_red == nullptr && p.tiles * 4 <= 3ll * ncu && g.KT >= 32) {
+    long long S = (2ll * ncu) / p.tiles;
+    if (S > g.KT / 8) S = g.KT / 8;
+    if (S > 1) {
+      p.kt_per = (int)cy_ceil_div(g.KT, S);
+      p.S = (int)cy_ceil_div(g.KT, p.kt_per);
+    }
+  }
+  return p;
+}
+GemmGeom gemm_geom(const cy_conv_gemm_t* a) {
+  GemmGeom g{};
+  g.K = a->TH * a->TW * a->Cin;
+  g.KT = (g.K + 31) / 32;
+  g.Np = (a->N + 63) / 64 * 64;
+  g.M = (long long)a->B * a->Ho * a->Wo;
+  g.corder = 1;        // measured on conv_3 (k4 s2, Cin 256): HBM fetch 22.4 GB per launch with taps outermost, -5 % time
+  g.S = 1; g.kt_per = g.KT; g.tiles = 0; g.ws = nullptr;
+  return g;
+}
+}  // namespace
+
+extern "C" long long cy_conv_gemm_ws_floats(const cy_conv_gemm_t* a) {
+  if (!a || a->B <= 0 || a->Ho <= 0 || a->Wo <= 0 || a->N <= 0 || a->Cin <= 0 || a->TH <= 0 || a->TW <= 0) return 0;
+  const GemmGeom g = gemm_geom(a);
+  const GemmPlan p = plan_gemm(a, g);
+  return p.S > 1 ? (long long)p.S * g.M * g.Np : 0;
+}
+
 extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   CY_REQUIRE(a && a->X && a->Wp && a->Y, "cy_conv_gemm: null pointer");
   CY_REQUIRE(a->B > 0 && a->Ho > 0 && a->Wo > 0 && a->N > 0 && a->Cin > 0 && a->TH > 0 && a->TW > 0,
@@ -709,12 +823,7 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   CY_REQUIRE(a->bn_red == nullptr || (a->bn_z && a->bn_scale && a->bn_shift && a->bn_mean && a->bn_invstd && a->N % 4 == 0 &&
                                       (((uintptr_t)a->Y | (uintptr_t)a->bn_z) & 15) == 0),
              "cy_conv_gemm: bn_red needs bn_z / scale / shift / mean / invstd, N %% 4 == 0 and 16-byte aligned Y, bn_z");
-  GemmGeom g;
-  g.K = a->TH * a->TW * a->Cin;
-  g.KT = (g.K + 31) / 32;
-  g.Np = (a->N + 63) / 64 * 64;
-  g.M = (long long)a->B * a->Ho * a->Wo;
-  g.corder = 1;        // measured on conv_3 (k4 s2, Cin 256): HBM fetch 22.4 GB per launch with taps outermost, -5 % time
+  GemmGeom g = gemm_geom(a);
   const bool vec = (a->xs_c == 1) && (a->Cin % 32 == 0) && (a->xs_x % 4 == 0) && (a->xs_y % 4 == 0) &&
                    (a->xs_b % 4 == 0) && (((uintptr_t)a->X & 15) == 0);
   if (!vec) {
@@ -724,13 +833,17 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
                "cy_conv_gemm: tap offsets out of range");
     CY_REQUIRE(a->Cin <= 65535, "cy_conv_gemm: scalar loader Cin too large");
   }
-  int ntw = (g.Np % 128 == 0) ? 2 : 1;
-  const long long mtiles = cy_ceil_div(g.M, BM);
-  // a grid far below the 256 CUs (CapsuleNet's primary-capsule convolution: 21 row tiles x 1 column tile of 128, 648 K
-  // steps each) gets 64-column tiles: twice the blocks
-  if (ntw == 2 && mtiles * (g.Np / 128) < 128) ntw = 1;
+  const GemmPlan plan = plan_gemm(a, g);
+  const int ntw = plan.ntw;
   const int BN = 64 * ntw;
-  const long long nblocks = mtiles * (g.Np / BN);
+  // the split of the reduction needs the caller's workspace (cy_conv_gemm_ws_floats); without one the layer runs unsplit
+  if (plan.S > 1 && a->ws != nullptr) {
+    CY_REQUIRE(a->ws_floats >= (long long)plan.S * g.M * g.Np && (((uintptr_t)a->ws) & 15) == 0,
+               "cy_conv_gemm: ws holds %lld floats, the split reduction needs %lld (cy_conv_gemm_ws_floats), 16-byte aligned",
+               a->ws_floats, (long long)plan.S * g.M * g.Np);
+    g.S = plan.S; g.kt_per = plan.kt_per; g.tiles = (int)plan.tiles; g.ws = a->ws;
+  }
+  const long long nblocks = plan.tiles * g.S;
   CY_REQUIRE(nblocks < (1ll << 31) && g.M < (1ll << 31), "cy_conv_gemm: grid too large");
   size_t lds = (size_t)(2 * 8 * A_KQ + 2 * 8 * (BN * 4 + 4)) * 4 + BM * 8 + (vec ? 0 : (size_t)g.KT * 32 * 4);
   hipStream_t s = (hipStream_t)stream;
@@ -747,6 +860,10 @@ extern "C" int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream) {
   else CY_GEMM_LAUNCH(1, false);
 #undef CY_GEMM_LAUNCH
   CY_LAUNCH_CHECK("cy_conv_gemm");
+  if (g.S > 1) {
+    conv_gemm_splitk_finish<<<(unsigned)cy_ceil_div(g.M * (g.Np / 4), 256), 256, 0, s>>>(*a, g);
+    CY_LAUNCH_CHECK("cy_conv_gemm (split-reduction finish)");
+  }
   return 0;
 }
 

@@ -25,9 +25,10 @@ class HipConv2d(nn.Module):
         self.weight = nn.Parameter(ref.weight.detach().clone())
         self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
         self.k, self.stride, self.padding = k, stride, padding
+        self.tag = 'conv'            # name of the layer in the kernel timer (ops.timer); the owner may set it
 
     def forward(self, x, nchw_in=False, slope=None):
-        cfg = ops.ConvBlockCfg(self.k, self.stride, self.padding, nchw_in, None, slope)
+        cfg = ops.ConvBlockCfg(self.k, self.stride, self.padding, nchw_in, None, slope, name=self.tag)
         return ops.conv_block(x, self.weight, self.bias, None, None, cfg)
 
 
@@ -180,7 +181,7 @@ class CapsuleLayer(nn.Module):
         w = torch.stack([c.weight for c in self.capsules], dim=1)
         w = w.reshape(-1, w.shape[2], self.kernel, self.kernel)
         b = torch.stack([c.bias for c in self.capsules], dim=1).reshape(-1)
-        cfg = ops.ConvBlockCfg(self.kernel, self.stride, 0, False, None, None)
+        cfg = ops.ConvBlockCfg(self.kernel, self.stride, 0, False, None, None, name='primary_caps')
         z = ops.conv_block(x, w, b, None, None, cfg)                      # [B,h,w,out_C*n_caps]
         return ops.squash(ops.primary_caps_rows(z, self.n_caps))         # [B, out_C*h*w, n_caps]
 
@@ -196,11 +197,13 @@ class Decoder(nn.Sequential):
                          HipConv2d(4, 8, 3, 1, 1), nn.Identity(), nn.Identity(),
                          HipConv2d(8, 16, 3, 1, 1), nn.Identity(),
                          HipConv2d(16, 3, 3, 1, 1), nn.Identity())
+        for i in (4, 7, 10, 12):
+            self[i].tag = 'dec_%d' % i
 
     def forward(self, t):
         B = t.shape[0]
         lin = self[0]
-        cfg = ops.ConvBlockCfg(1, 1, 0, False, None, 0.0)
+        cfg = ops.ConvBlockCfg(1, 1, 0, False, None, 0.0, name='dec_fc')
         h = ops.conv_block(t.view(B, 1, 1, 16), lin.weight.view(256, 16, 1, 1), lin.bias, None, None, cfg)  # ReLU fused
         h = ops.nchw_to_nhwc(h.view(B, 16, 4, 4))                      # UnFlatten(16,4,4) is an NCHW view
         h = self[4](ops.upsample_nearest(h, 2), slope=0.0)
@@ -217,6 +220,7 @@ class CapsuleNet(nn.Module):
         super().__init__()
         n_iter = getattr(params, 'n_iter', 3)
         self.conv1 = HipConv2d(3, 256, 9)
+        self.conv1.tag = 'conv1'
         self.primary_capsules = CapsuleLayer(params, n_caps=8, n_nodes=-1, in_C=256, out_C=16, kernel=8, stride=2)
         self.traffic_sign_capsules = CapsuleLayer(params, n_caps=params.n_classes, n_nodes=16 * 9 * 9, in_C=8,
                                                   out_C=16, n_iter=n_iter)

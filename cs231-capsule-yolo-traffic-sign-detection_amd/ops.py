@@ -250,9 +250,22 @@ def conv_forward(x, weight, bias, k, stride, pad, nchw=False, stats=None, relu=F
                  xs_b=xs[0], xs_y=xs[1], xs_x=xs[2], xs_c=xs[3], B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, N=Cout,
                  TH=k, TW=k, in_stride=stride, dy0=-pad, dx0=-pad, dstep=1,
                  Hy=Ho, Wy=Wo, out_stride=1, out_oy=0, out_ox=0, act=1 if relu else 2 if lrelu is not None else 0, act_slope=osl)
+    ws = _gemm_workspace(a, x)
     with timer.range('conv_gemm_fwd/' + tag):
         call('cy_conv_gemm', C.byref(a), st)
+    del ws
     return z
+
+
+def _gemm_workspace(a, like):
+    """The optional workspace of one cy_conv_gemm launch (split reduction of under-filled grids, capsyolo_hip.h); the returned tensor
+    must stay referenced until the call has been issued."""
+    n = query('cy_conv_gemm_ws_floats', C.byref(a))
+    if n <= 0:
+        return None
+    ws = _empty((n,), like)
+    a.ws, a.ws_floats = ws.data_ptr(), n
+    return ws
 
 
 def dgrad_classes(Hi, Wi, k, stride, pad):
@@ -328,8 +341,10 @@ def conv_dgrad(dz, weight, in_shape, k, stride, pad, tag='conv', bn_fuse=None, i
             bz, bsc, bsh, bmu, bis, bsl, bred = bn_fuse
             a.bn_z, a.bn_scale, a.bn_shift = bz.data_ptr(), bsc.data_ptr(), bsh.data_ptr()
             a.bn_mean, a.bn_invstd, a.bn_red, a.bn_slope = bmu.data_ptr(), bis.data_ptr(), bred.data_ptr(), float(bsl)
+        ws = _gemm_workspace(a, dz)
         with timer.range('conv_gemm_dgrad/' + tag):
             call('cy_conv_gemm', C.byref(a), st)
+        del ws
     return dx
 
 

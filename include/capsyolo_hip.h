@@ -59,6 +59,11 @@ typedef struct {
   float bn_slope;
   float act_slope;    /* act == 2: Y = max(v, act_slope * v), 0 <= act_slope <= 1 -- the eval-mode forward of a conv -> BatchNorm ->
                        * LeakyReLU block whose BatchNorm was folded into weights and bias (cy_bn_fold_eval) */
+  /* Optional workspace of cy_conv_gemm (fp32): ws_floats >= cy_conv_gemm_ws_floats(a) floats, 16-byte aligned.  A layer whose
+   * output grid is far below the chip (CapsuleNet's primary-capsule convolution, models.py:60-62: 42 tiles, K = 20736) then runs
+   * several blocks per tile on shares of the reduction; the shares' partial sums are added in a fixed order (deterministic).
+   * NULL / 0: never split. */
+  float* ws; long long ws_floats;
 } cy_conv_gemm_t;
 
 /* First layer of the backbones (models.py:347-349 DarkCapsuleNet conv_1 3 -> 128, models.py:132-136 DarkNet conv_1
@@ -135,6 +140,7 @@ int cy_conv_pack_weights(const float* W, float* Wp, int Cout, int Cin, int KH, i
  * launch was bound by exactly that); cy_bn_finalize adds the copies up. */
 #define CY_STATS_COPIES 16
 int cy_conv_gemm(const cy_conv_gemm_t* a, void* stream);
+long long cy_conv_gemm_ws_floats(const cy_conv_gemm_t* a);   /* 0: this launch does not split its reduction */
 
 /* weight gradient: dW[Cout][Cin][KH][KW] = sum over pixels of X-patch (x) dZ.
  * slabs: workspace of cy_conv_wgrad_ws_floats() floats.  dZ is NHWC [B,Ho,Wo,N] contiguous. */

@@ -65,6 +65,48 @@ def test_conv_fwd_dgrad_wgrad(case):
         close(dx.permute(0, 3, 1, 2), xd.grad, 5e-5, 5e-5)
 
 
+@pytest.mark.parametrize('case', [(32, 256, 24, 128, 8, 2, 0), (5, 480, 7, 224, 5, 1, 2), (2, 1024, 4, 10, 1, 1, 0)])
+def test_conv_gemm_split_reduction(case, monkeypatch):
+    """Under-filled grids split their reduction over several blocks per output tile (cy_conv_gemm_ws_floats > 0; round 4): the
+    CapsuleNet primary-capsule convolution at its full shape (batch 32: 42 tiles x 648 K tiles -> 12 shares), a padded-N layer with
+    a ragged last share, the 1x1 head.  Forward and input gradient against torch fp64, against the unsplit launch of the same
+    kernel (no workspace), and bit-identical on repetition (the shares are added in a fixed order)."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import ConvGemm, query
+    import ctypes as C
+    B, Cin, H, Cout, k, s, p = case
+    x = rnd((B, Cin, H, H), 1)
+    w = rnd((Cout, Cin, k, k), 2, (1.0 / (Cin * k * k)) ** 0.5)
+    b = rnd((Cout,), 3, 0.1)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    zr = F.conv2d(xd, wd, b.double(), stride=s, padding=p)
+    gz = rnd(tuple(zr.shape), 4)
+    zr.backward(gz.double())
+    xg, wg, bg = x.permute(0, 2, 3, 1).contiguous().to(dev()), w.to(dev()), b.to(dev())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    seen = []
+    orig = ops._gemm_workspace
+
+    def spy(a, like):
+        ws = orig(a, like)
+        seen.append(0 if ws is None else ws.numel())
+        return ws
+    monkeypatch.setattr(ops, '_gemm_workspace', spy)
+    z = ops.conv_forward(xg, wg, bg, k, s, p, False)
+    dx = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), k, s, p)
+    assert seen and seen[0] > 0, seen                          # the forward did split
+    z2 = ops.conv_forward(xg, wg, bg, k, s, p, False)
+    dx2 = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), k, s, p)
+    assert torch.equal(z, z2) and torch.equal(dx, dx2)
+    monkeypatch.setattr(ops, '_gemm_workspace', lambda a, like: None)
+    z1 = ops.conv_forward(xg, wg, bg, k, s, p, False)
+    dx1 = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), k, s, p)
+    close(z.permute(0, 3, 1, 2), zr, 2e-5, 2e-5)
+    close(dx.permute(0, 3, 1, 2), xd.grad, 5e-5, 5e-5)
+    close(z, z1, 1e-5, 1e-5)
+    close(dx, dx1, 1e-5, 1e-5)
+
+
 @pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10),
                                   (3, 8, 200, 64), (2, 16, 104, 128)])   # > 256 tiles: persistent blocks walk several tiles
 @pytest.mark.parametrize('f4', [False, True])
