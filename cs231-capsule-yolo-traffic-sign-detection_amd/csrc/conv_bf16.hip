@@ -608,8 +608,9 @@ extern "C" int cy_conv_gemm_bf16_classes(const cy_conv_gemm_t* a, int ncls, int 
       CY_REQUIRE(q->X == a->X && q->Y == a->Y && q->bias == a->bias && q->stats == a->stats && q->B == a->B && q->Hi == a->Hi &&
                  q->Wi == a->Wi && q->Cin == a->Cin && q->Ho == a->Ho && q->Wo == a->Wo && q->N == a->N && q->TH == a->TH &&
                  q->TW == a->TW && q->in_stride == a->in_stride && q->dstep == a->dstep && q->Hy == a->Hy && q->Wy == a->Wy &&
-                 q->out_stride == a->out_stride && q->act == a->act && q->bn_red == a->bn_red && q->bn_z == a->bn_z && q->Wp &&
-                 (((uintptr_t)q->Wp) & 15) == 0,
+                 q->out_stride == a->out_stride && q->act == a->act && q->act_slope == a->act_slope && q->bn_red == a->bn_red &&
+                 q->bn_z == a->bn_z && q->bn_scale == a->bn_scale && q->bn_shift == a->bn_shift && q->bn_mean == a->bn_mean &&
+                 q->bn_invstd == a->bn_invstd && q->bn_slope == a->bn_slope && q->Wp && (((uintptr_t)q->Wp) & 15) == 0,
                  "cy_conv_gemm_bf16_classes: class %d differs from class 0 in more than Wp / dy0 / dx0 / out_oy / out_ox", c);
     }
     g.c_dy0[c] = q->dy0; g.c_dx0[c] = q->dx0; g.c_oy[c] = q->out_oy; g.c_ox[c] = q->out_ox; g.c_wp[c] = (const u16*)q->Wp;

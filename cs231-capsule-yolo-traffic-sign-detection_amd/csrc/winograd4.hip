@@ -15,11 +15,12 @@
 //   * every thread transforms HALF an item (tile, channel pair): rows 0..2 or 3..5 of V = B^T d B (72 v_pk_fma_f32) and
 //     writes them into the A-operand image V[pos][k pair][tile slot (swizzled)][tile half][2 k-steps],
 //   * the transformed weights never touch LDS: they are packed per call in the B-operand order of each wave
-//     (U[co block][chunk][wave][position pair][lane][4]) and stream global/L2 -> registers through a ring of 6
-//     dwordx4 loads per wave, each issued 48 MFMAs before its first use.
+//     (U[co block][chunk][wave][position pair][lane][4]) and stream global/L2 -> registers through a ring of F4_NBR (9)
+//     dwordx4 loads per wave, each issued F4_NBR position pairs (72 MFMAs) before its first use.
 // The grid is persistent (one block per CU, XCD-aware tile order); a block walks its tiles as one continuous stream of
 // chunks (winograd_s2.hip: the loads and the input transform of the next tile's first chunks run under the MFMAs of
-// the current tile's last chunks).  All LDS and global accesses of the loop are plain loads / stores that hipcc counts.
+// the current tile's last chunks).  The loop's global loads (input patch, B-operand ring of F4_NBR position pairs) are inline asm
+// with hand-counted `s_waitcnt vmcnt(N)` (hipcc's own bookkeeping drew vmcnt(0) at the loop header); tools/check_vmcnt.py replays them.
 #include <type_traits>
 #include "common.h"
 
@@ -42,6 +43,8 @@ constexpr int F4_NQ = 5;                        // patch float4 items per thread
 #define CY_F4_NBR 9
 #endif
 constexpr int F4_NBR = CY_F4_NBR;              // ring of B-operand loads per wave (position pairs in flight; divides 18)
+static_assert(18 % F4_NBR == 0 && F4_NBR >= 1 && F4_NBR <= 18 && (F4_NBR + 3) / 4 <= 5,
+              "winograd4: the ring-slot identity (k + NBR - 18) % NBR == k % NBR and the hand-counted vmcnt schedule need NBR | 18");
 constexpr int F4_OG = 272;                      // floats per lane group of the drain scratch: 16 pixels x 16 channels + 16 pad
 constexpr int F4_OSTEP = 4 * F4_OG;             // one drain step of a wave
 constexpr int F4_BAR = 136;                     // slot of the chunk's only barrier (the MFMAs behind it read registers only)
@@ -105,7 +108,7 @@ __device__ __forceinline__ float acc_elem4(float a_elem) {    // one accumulator
 // ---- compile-time schedule of one chunk: 144 slots; slot s issues the MFMA of position s >> 2, tile half s & 1, k-step
 // (s >> 1) & 1 (consecutive MFMAs alternate between the position's two accumulators).  The A fragment of position p + 2 (both
 // tile halves, both k-steps: one ds_read_b128) is fetched in slot 4p.  Side work, one piece per slot, only in slots 4p + 2 and 4p + 3:
-//   1 G_B    B operand of position pair q + 6 (ring slot q % 6), right behind the last MFMA of pair q
+//   1 G_B    B operand of position pair q + F4_NBR (ring slot q % F4_NBR), right behind the last MFMA of pair q
 //   3 S_raw  one float4 of the patch of chunk f + 2: registers -> LDS        2 G_raw  one patch load of chunk f + 3
 //   4 T_rd   one column (7 float2) of the thread's patch of chunk f + 1      5 T_col  half a column of T = B^T d
 //   6 T_row  a quarter of one row of V = T B (3 packed FMAs; the last two quarters store 3 positions each)
@@ -152,8 +155,8 @@ constexpr int f4_slot_of(int kind, int idx) {
   for (int i = 0; i < 144; ++i) if (F4S.kind[i] == kind && F4S.idx[i] == idx) return i;
   return -1;
 }
-// operations younger than the load of position pair q when its first MFMA (slot 8 q) issues: the pair was loaded by G_B(q - 6)
-// of this chunk or G_B(q + 12) of the previous one (the prologue issues pairs 0..5 in the same order, behind its patch loads)
+// operations younger than the load of position pair q when its first MFMA (slot 8 q) issues: the pair was loaded by G_B(q - F4_NBR)
+// of this chunk or G_B(q + 18 - F4_NBR) of the previous one (the prologue issues pairs 0 .. F4_NBR - 1 in the same order, behind its patch loads)
 constexpr int f4_younger_b(int q) {
   return q >= F4_NBR ? f4_vm_between(f4_slot_of(1, q - F4_NBR) + 1, 8 * q)
                      : f4_vm_between(f4_slot_of(1, q + 18 - F4_NBR) + 1, 144) + f4_vm_between(0, 8 * q);
@@ -305,7 +308,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(Wino4Args a) {
   };
 
   // ---- prologue (once per block).  State at the top of stream position f (tile km, chunk cm): V[f&1] = position f,
-  // raw[(f+1)&1] = patch of f+1, graw = patch of f+2, patch cursor (kr, cr) at f+3; bq = position pairs 0..5 of f,
+  // raw[(f+1)&1] = patch of f+1, graw = patch of f+2, patch cursor (kr, cr) at f+3; bq = position pairs 0 .. F4_NBR - 1 of f,
   // up_cur / up_nxt = this wave's U of positions f / f+1.
   {
     f32x4 graw1[F4_NQ];

@@ -562,7 +562,9 @@ int g4_nrange(int B, int H, int W, int Cin, int Cout) {
   const long long tiles = ((long long)B * (H / 4) * (W / 16) + 1) / 2;   // chunk pairs
   const int per = (Cin / 32) * (Cout / 64);
   long long n = ncu / per;
-  if (const char* e = getenv("CY_G4_NRANGE")) n = atoll(e);            // developer override (tests of the range logic)
+#ifdef CY_G4_NRANGE_ENV
+  if (const char* e = getenv("CY_G4_NRANGE")) n = atoll(e);            // developer override (builds with -DCY_G4_NRANGE_ENV only)
+#endif
   if (n < 1) n = 1;
   if (n > tiles) n = tiles;
   return (int)n;

@@ -44,6 +44,17 @@ class HipBatchNorm2d(nn.Module):
         self.register_buffer('num_batches_tracked', torch.tensor(0, dtype=torch.long))
         self.momentum, self.eps = momentum, eps
 
+    # The eval-mode fold cache (ops.fold_eval_bn) is keyed by the tensors' version counters, which a write through `param.data`
+    # (manual initialisation, EMA, clipping, c10d's parameter broadcast) does not bump: every switch of mode and every state-dict
+    # load therefore starts a new cache epoch -- an eval forward never sees W' / b' folded from older values.
+    def train(self, mode=True):
+        ops._bump_param_epoch()
+        return super().train(mode)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        ops._bump_param_epoch()
+        return super()._load_from_state_dict(*args, **kwargs)
+
 
 class HipLeakyReLU(nn.Module):
     def __init__(self, slope):
