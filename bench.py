@@ -405,11 +405,22 @@ def secondary(dev, steps=5):
     _timed_steps(step0, 0, 3)
     ops.timer.enabled = False
     kt = ops.timer.summary()
+    # the same step captured once in a HIP graph and replayed (capsyolo_amd/graph_step.py; main.py --graph): the model is launch-bound
+    from capsyolo_amd.graph_step import GraphedStep
+
+    def fwd0(m, xb, yb):
+        sc, rec = m(xb, yb, True)
+        return sc, loss_fns.capsule_loss(sc, yb, p, xb, rec)
+    gstep = GraphedStep(net, fwd0, opt, (x, y))
+    dtg, finalg = _timed_steps(lambda: gstep(x, y)[1], 5, 4 * steps)
     out['capsule_32_b32_f32'] = {
         'config': {'workload': 'experiments/capsule GTSRB-shaped 32x32, 43 classes, 3 routing iters, batch 32, recon on, fp32 '
                                '(BASELINE configs[0] on the GPU)'},
         'value': round(B / dt, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dt, 3), 'steps': 4 * steps, 'warmup': 5,
         'dtype': 'f32', 'final_loss': round(final, 6),
+        'hip_graph_replay': {'value': round(B / dtg, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dtg, 3), 'steps': 4 * steps,
+                             'final_loss': round(finalg, 6), 'note': 'forward + loss + backward + Adam captured once (torch.cuda.graph over '
+                             'the C-ABI launches), replayed per step; batch and optimizer scalars through device memory'},
         'kernel_ms_per_step': dict((k, round(ms * cnt / 3, 4)) for k, (cnt, ms) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8])}
     del net, opt, x, y
     torch.cuda.empty_cache()

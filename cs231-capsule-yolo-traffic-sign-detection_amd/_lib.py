@@ -129,6 +129,7 @@ _SIGS = {
     'cy_cast_bf16_f32': [_P, _P, _L, _P],
     'cy_multi_copy': [_P, _P, _I, _I, _P, _I, _F, _P],
     'cy_adam_multi': [_P, _P, _I, _I, _F, _F, _F, _F, _F, _F, _P],
+    'cy_adam_multi_dev': [_P, _P, _I, _I, _P, _P],
 }
 _RET = {
     'capsyolo_last_error': (C.c_char_p, []),

@@ -29,6 +29,29 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const AdamEntry* __rest
   }
 }
 
+// The same step with its scalars read from DEVICE memory: hyper = {lr, beta1, beta2, eps, bias_corr1, bias_corr2}.  A captured HIP
+// graph freezes kernel arguments; the step count (bias corrections) and a scheduler's learning rate change from step to step, so
+// the host refreshes the six floats with one small copy in front of every replay (graph_step.py).
+__global__ __launch_bounds__(256) void adam_multi_dev_kernel(const AdamEntry* __restrict__ table, const int2* __restrict__ blockmap,
+                                                             int chunk, const float* __restrict__ hyper) {
+  const float beta1 = hyper[1], beta2 = hyper[2], eps = hyper[3];
+  const float step_size = hyper[0] / hyper[4], inv_bc2_sqrt = 1.f / sqrtf(hyper[5]);
+  const int2 bm = blockmap[blockIdx.x];
+  const AdamEntry e = table[bm.x];
+  const long long begin = (long long)bm.y * chunk;
+  long long end = begin + chunk;
+  if (end > e.n) end = e.n;
+  for (long long i = begin + threadIdx.x; i < end; i += 256) {
+    const float g = e.g[i];
+    const float m = beta1 * e.m[i] + (1.f - beta1) * g;
+    const float v = beta2 * e.v[i] + (1.f - beta2) * g * g;
+    e.m[i] = m;
+    e.v[i] = v;
+    const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
+    e.p[i] -= step_size * (m / denom);
+  }
+}
+
 // flat[offset_k + i] = scale * tensor_k[i] (pack) or tensor_k[i] = scale * flat[offset_k + i] (unpack) for a whole list
 // of tensors in one launch: table[k] = {tensor*, offset into flat, numel}, blockmap as above
 struct CopyEntry { float* t; long long off; long long n; };
@@ -64,5 +87,12 @@ extern "C" int cy_adam_multi(const void* table, const void* blockmap, int n_bloc
                                                                lr / bias_corr1, beta1, beta2, eps,
                                                                1.f / sqrtf(bias_corr2));
   CY_LAUNCH_CHECK("cy_adam_multi");
+  return 0;
+}
+
+extern "C" int cy_adam_multi_dev(const void* table, const void* blockmap, int n_blocks, int chunk, const float* hyper, void* stream) {
+  CY_REQUIRE(table && blockmap && hyper && n_blocks > 0 && chunk > 0, "cy_adam_multi_dev: bad arguments");
+  adam_multi_dev_kernel<<<n_blocks, 256, 0, (hipStream_t)stream>>>((const AdamEntry*)table, (const int2*)blockmap, chunk, hyper);
+  CY_LAUNCH_CHECK("cy_adam_multi_dev");
   return 0;
 }

@@ -436,6 +436,9 @@ int cy_multi_copy(const void* table, const void* blockmap, int n_blocks, int chu
 int cy_adam_multi(const void* table, const void* blockmap, int n_blocks, int chunk,
                   float lr, float beta1, float beta2, float eps, float bias_corr1, float bias_corr2,
                   void* stream);
+/* The same step with its six scalars {lr, beta1, beta2, eps, bias_corr1, bias_corr2} read from device memory (hyper): for a
+ * training step captured in a HIP graph, whose kernel arguments are frozen (the host refreshes hyper before every replay). */
+int cy_adam_multi_dev(const void* table, const void* blockmap, int n_blocks, int chunk, const float* hyper, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,9 @@ parser.add_argument('--npy', default=False, help='data is npy file', action='sto
 parser.add_argument('--synthetic', type=int, default=0, help='use N synthetic samples instead of data/')
 parser.add_argument('--n_epochs', type=int, default=0, help='override params.json n_epochs')
 parser.add_argument('--batch_size', type=int, default=0, help='override params.json batch_size')
+parser.add_argument('--graph', action='store_true',
+                    help='capture the training step (forward + loss + backward + Adam) once in a HIP graph and replay it per batch: '
+                         'for the launch-bound small models (capsule); single process only')
 parser.add_argument('--fix_ckpt_dir', action='store_true',
                     help='save checkpoints into model_dir (where --restore reads) instead of model_dir + str(train_frac)')
 
@@ -172,7 +175,23 @@ def train(x, y, model, optimizer, loss_fn, metric, params, bucket, if_eval=True)
     n_batch, it = _batches(x, y, params.batch_size)
     avg_loss, avg_iou, y_hat, y_true = 0.0, 0.0, [], []
     want_metric = if_eval and metric is not None
+    graphed = getattr(params, 'graph', False) and params.world == 1 and params.device != 'cpu'
     for x_bch, y_bch in _feed(it, params):
+        if graphed:
+            # the whole step as one graph replay (capsyolo_amd/graph_step.py); captured on the first batch of this shape
+            key = (id(model), id(optimizer), tuple(x_bch.shape), tuple(y_bch.shape))
+            if getattr(params, '_graph_key', None) != key:
+                from capsyolo_amd.graph_step import GraphedStep
+                params._graph_step = GraphedStep(model, lambda m, xb, yb: _forward(m, loss_fn, xb, yb, params), optimizer, (x_bch, y_bch))
+                params._graph_key = key
+            y_hat_bch, loss = params._graph_step(x_bch, y_bch)
+            if want_metric:
+                y_hat.append(y_hat_bch.detach().clone())  # the graph's output tensor is overwritten by the next replay
+                y_true.append(y_bch.detach().clone())
+            avg_loss += loss.item() / n_batch
+            if params.model == 'darknet_d':
+                avg_iou += params.avg_iou.item() / n_batch
+            continue
         y_hat_bch, loss = _forward(model, loss_fn, x_bch, y_bch, params)
         if want_metric:
             y_hat.append(y_hat_bch.detach())
@@ -274,6 +293,7 @@ def load_params(model_dir, args):
     if args.batch_size:
         params.batch_size = args.batch_size
     params.fix_ckpt_dir = args.fix_ckpt_dir
+    params.graph = args.graph
     return params
 
 
