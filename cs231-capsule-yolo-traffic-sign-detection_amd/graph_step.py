@@ -35,7 +35,11 @@ class GraphedStep(object):
         self._ring_events, self._ring_pos = [None] * 8, 0
         self._hyper_dev = dict((id(g), torch.zeros(6, dtype=torch.float32, device=dev)) for g in optimizer.param_groups)
         # eager warm-up steps on a side stream (torch's capture recipe): optimizer state, the zero pool and the kernels' one-time
-        # attribute calls (cy_allow_lds) exist before the capture begins
+        # attribute calls (cy_allow_lds) exist before the capture begins.  They must not train: parameters, buffers (BatchNorm running
+        # statistics) and optimizer state are put back IN PLACE afterwards (the capture holds their addresses).
+        snap_model = dict((k, v.detach().clone()) for k, v in model.state_dict().items())
+        snap_opt = dict((p, dict((k, (v.detach().clone() if torch.is_tensor(v) else v)) for k, v in optimizer.state[p].items()))
+                        for g in optimizer.param_groups for p in g['params'] if p in optimizer.state and len(optimizer.state[p]))
         s = torch.cuda.Stream(device=dev)
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
@@ -43,6 +47,21 @@ class GraphedStep(object):
                 self._eager(*self.static)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
+        with torch.no_grad():
+            for k, v in model.state_dict().items():
+                v.copy_(snap_model[k])
+            for g in optimizer.param_groups:
+                for p in g['params']:
+                    st = optimizer.state.get(p)
+                    if not st:
+                        continue
+                    old = snap_opt.get(p)
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(old[k]) if old is not None else v.zero_()
+                        else:
+                            st[k] = old[k] if old is not None else 0
+        ops._bump_param_epoch()
         self.graph = torch.cuda.CUDAGraph()
         self._refresh_scalars(advance=False)          # valid numbers during the capture (they are not read until a replay)
         optimizer.graph_hyper = self._hyper_dev

@@ -180,11 +180,11 @@ def train(x, y, model, optimizer, loss_fn, metric, params, bucket, if_eval=True)
         if graphed:
             # the whole step as one graph replay (capsyolo_amd/graph_step.py); captured on the first batch of this shape
             key = (id(model), id(optimizer), tuple(x_bch.shape), tuple(y_bch.shape))
-            if getattr(params, '_graph_key', None) != key:
+            steps = params.__dict__.setdefault('_graph_steps', {})
+            if key not in steps:                          # (one capture per batch shape: the ragged last batch gets its own)
                 from capsyolo_amd.graph_step import GraphedStep
-                params._graph_step = GraphedStep(model, lambda m, xb, yb: _forward(m, loss_fn, xb, yb, params), optimizer, (x_bch, y_bch))
-                params._graph_key = key
-            y_hat_bch, loss = params._graph_step(x_bch, y_bch)
+                steps[key] = GraphedStep(model, lambda m, xb, yb: _forward(m, loss_fn, xb, yb, params), optimizer, (x_bch, y_bch))
+            y_hat_bch, loss = steps[key](x_bch, y_bch)
             if want_metric:
                 y_hat.append(y_hat_bch.detach().clone())  # the graph's output tensor is overwritten by the next replay
                 y_true.append(y_bch.detach().clone())
