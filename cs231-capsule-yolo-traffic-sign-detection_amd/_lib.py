@@ -67,6 +67,7 @@ _SIGS = {
     'cy_conv1_bn_bwd_wgrad_bf16': [_P, _P, _P, _P, _P, _P, _P, _P, _F, _P, _L, _P, _P, _I, _I, _I, _I, _P],
     'cy_conv1_3x3_fwd_act_bf16': [_P, _P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
+    'cy_conv3x3_winograd_ws': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P, _L, _P],
     'cy_wino4_pack_weights': [_P, _P, _I, _I, _I, _P],
     'cy_conv3x3_winograd4': [_P, _P, _P, _P, _P, _F, _I, _I, _I, _I, _I, _P],
     'cy_conv3x3_winograd4_wgrad': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
@@ -138,6 +139,7 @@ _RET = {
     'cy_conv_bf16_packed_elems': (_L, [_I, _I]),
     'cy_conv_wgrad_bf16_ws_floats': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'cy_wino_packed_floats': (_L, [_I, _I]),
+    'cy_wino_split_ws_floats': (_L, [_I, _I, _I, _I, _I, _I]),
     'cy_wino4_packed_floats': (_L, [_I, _I]),
     'cy_wino4_wgrad_ws_floats': (_L, [_I, _I, _I, _I, _I]),
     'cy_wino4_wgrad_ok': (_I, [_I, _I, _I, _I, _I]),

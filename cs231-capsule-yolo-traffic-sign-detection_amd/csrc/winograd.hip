@@ -49,6 +49,11 @@ struct WinoArgs {
   int B, H, W, Cin, Cout, Np, tbh, tbw;
   int ntiles;                               // B * tbh * tbw * Np/64 output tiles, walked by a persistent grid
   float out_slope;                          // EPI == 2: Y = lrelu(conv + bias) with this slope (eval mode, BatchNorm folded into U / bias)
+  // split of the reduction (round 4; grid.y = shares): a launch whose tiles fill at most half the CUs (DarkNet's 13 x 13 input
+  // gradients: 128 tiles) runs grid.y blocks per tile, share y on input channels y * Cin .. (y + 1) * Cin - 1 of the Cs channels a pixel
+  // has, into its own slab Y + y * yslab; wino_split_sum adds the slabs in share order
+  int Cs;
+  long long yslab;
 };
 
 __device__ __forceinline__ f32x16 mfma_zero() {
@@ -216,6 +221,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int nblk = a.Np / WN;
   const int ntile_mine = (a.ntiles - (int)vid + (int)gridDim.x - 1) / (int)gridDim.x;   // >= 1 (grid <= ntiles)
   const int nchunk = a.Cin / KC;
+  const int share = blockIdx.y;                        // (0 unless the reduction is split)
+  const int c0 = share * nchunk;                       // this share's first chunk of U
   struct TilePos { int nb, b, oy0, ox0; };
   auto tile_pos = [&](int k) {              // k-th tile of this block (uniform)
     const int id = (int)vid + k * (int)gridDim.x;
@@ -250,12 +257,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
   const int kq_of_thread = (t >> 4) & 1;    // 256 q keeps bit 4 of the item
   auto set_raw_tile = [&](int k) {
     const TilePos p = tile_pos(k);
-    const char* img = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cin) + kq_of_thread * 16;
+    const char* img = (const char*)(a.X + (long long)p.b * a.H * a.W * a.Cs + (long long)share * a.Cin) + kq_of_thread * 16;
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       const int iy = p.oy0 - 1 + rpy[q], ix = p.ox0 - 1 + rpx[q];
       const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-      gptr[q] = ok ? img + (size_t)((iy * a.W + ix) * a.Cin) * 4 : (const char*)wino_zero_pad + kq_of_thread * 16;
+      gptr[q] = ok ? img + (size_t)((iy * a.W + ix) * a.Cs) * 4 : (const char*)wino_zero_pad + kq_of_thread * 16;
     }
   };
   // stream cursors (tile index within this block, chunk): advance by one chunk, stop at the very last chunk
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     float* ub = Us + buf * VU_BUF + uslab;
 #pragma unroll
     for (int q = 0; q < 8; ++q)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + ((long long)c * uchunk + q * useg) * 4 + uvoff),
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ubase + ((long long)(c + c0) * uchunk + q * useg) * 4 + uvoff),
                                        (__attribute__((address_space(3))) void*)(ub + q * 4 * SLAB), 16, 0, 0);
   };
   auto Sraw = [&](int c, const f32x4 (&src)[3]) {   // registers -> LDS raw patch buffer c & 1
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
     float* vw_ = Vs + ((c + 1) & 1) * VU_BUF + vdst;                // ... and writes (harmless after the last position)
     const size_t gx = (size_t)cr * (KC * 4);                        // G_raw(f+3) (the cursors stop at the last position:
                                                                     //  the tail re-loads valid data), uniform
-    const char* gusrc = ubase + (long long)cu * uchunk * 4;         // D_U(f+1), uniform (harmless after the last position)
+    const char* gusrc = ubase + (long long)(cu + c0) * uchunk * 4;    // D_U(f+1), uniform (harmless after the last position)
     float* uw_ = Us + ((c + 1) & 1) * VU_BUF + uslab;
     float* rw_ = Rs + (c & 1) * RAW_BUF;                            // S_raw(f+2) -> raw[(f+2)&1]
     const float* vn_ = Vs + ((c + 1) & 1) * VU_BUF + fragA;         // fragments of position f+1
@@ -518,7 +525,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
       const int cbase = nb * WN + wn * 32 + c4 * 4;
       const bool vec_ok = (a.Cout & 3) == 0;
       if (full) {                             // whole block inside the image: one base pointer, no checks
-        float* ybase = a.Y + (((long long)b * a.H + oy0) * a.W + ox0) * a.Cout + cbase;
+        float* ybase = a.Y + (long long)share * a.yslab + (((long long)b * a.H + oy0) * a.W + ox0) * a.Cout + cbase;
   #pragma unroll
         for (int it = 0; it < 16; ++it) {
           const int p = it * 8 + (lane >> 3);
@@ -535,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(WinoArgs a) {
           const int oy = oy0 + 2 * (tl >> 3) + (ab >> 1), ox = ox0 + 2 * (tl & 7) + (ab & 1);
           const f32x4 v = *(const f32x4*)(ow + p * 32 + c4 * 4);
           if (oy < a.H && ox < a.W) {
-            float* yp = a.Y + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + cbase;
+            float* yp = a.Y + (long long)share * a.yslab + (((long long)b * a.H + oy) * a.W + ox) * a.Cout + cbase;
             if (vec_ok && cbase + 3 < a.Cout) *(f32x4*)yp = v;
             else {
   #pragma unroll
@@ -1146,8 +1153,41 @@ extern "C" int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin,
   return 0;
 }
 
+namespace {
+// out[i] = sum over the shares' slabs, in share order (deterministic)
+__global__ void wino_split_sum_kernel(const float* __restrict__ ws, float* __restrict__ Y, int S, long long n4) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  f32x4 v = ((const f32x4*)ws)[i];
+  for (int k = 1; k < S; ++k) v += ((const f32x4*)ws)[(long long)k * n4 + i];
+  ((f32x4*)Y)[i] = v;
+}
+// shares of the reduction for a launch without an epilogue (input gradients): at most 4, at least 16 chunks of 8 channels each
+int wino_shares(int B, int H, int W, int Cin, int Cout, int plain) {
+  if (!plain || Cout % 4 != 0) return 1;
+  int dev = 0, ncu = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) return 1;
+  const long long tiles = (long long)B * ((H + 15) / 16) * ((W + 15) / 16) * ((Cout + 63) / 64);
+  long long S = ncu / (tiles > 0 ? tiles : 1);
+  if (S > 4) S = 4;
+  while (S > 1 && (Cin % (KC * S) != 0 || Cin / (KC * S) < 16)) --S;
+  return S < 1 ? 1 : (int)S;
+}
+}  // namespace
+
+extern "C" long long cy_wino_split_ws_floats(int B, int H, int W, int Cin, int Cout, int plain) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return 0;
+  const int S = wino_shares(B, H, W, Cin, Cout, plain);
+  return S > 1 ? (long long)S * B * H * W * Cout : 0;
+}
+
 extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
                                    int B, int H, int W, int Cin, int Cout, void* stream) {
+  return cy_conv3x3_winograd_ws(X, U, Y, bias, stats, out_slope, B, H, W, Cin, Cout, nullptr, 0, stream);
+}
+
+extern "C" int cy_conv3x3_winograd_ws(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
+                                      int B, int H, int W, int Cin, int Cout, float* ws, long long ws_floats, void* stream) {
   CY_REQUIRE(X && U && Y && B > 0 && H > 0 && W > 0 && Cout > 0, "cy_conv3x3_winograd: bad arguments");
   CY_REQUIRE(out_slope >= 0.f && out_slope <= 1.f, "cy_conv3x3_winograd: out_slope=%g must be in [0, 1] (1 = no activation)", (double)out_slope);
   CY_REQUIRE(out_slope == 1.f || stats == nullptr, "cy_conv3x3_winograd: the activation epilogue is for eval-mode forwards (no statistics)");
@@ -1158,11 +1198,22 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
              "cy_conv3x3_winograd: image too large for 32-bit byte offsets");
   WinoArgs a;
   a.X = X; a.U = U; a.Y = Y; a.bias = bias; a.stats = stats; a.out_slope = out_slope;
-  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.Cs = Cin; a.yslab = 0;
   a.Np = (Cout + 63) / 64 * 64;
   a.tbh = (H + 15) / 16; a.tbw = (W + 15) / 16;
   const long long tiles = (long long)B * a.tbh * a.tbw * (a.Np / WN);
   CY_REQUIRE(tiles < (1ll << 31), "cy_conv3x3_winograd: too many tiles");
+  // with a workspace, a launch without an epilogue that fills at most half the chip splits its reduction (cy_wino_split_ws_floats)
+  int S = 1;
+  if (ws != nullptr) {
+    S = wino_shares(B, H, W, Cin, Cout, bias == nullptr && stats == nullptr && out_slope == 1.f);
+    if (S > 1) {
+      CY_REQUIRE(ws_floats >= (long long)S * B * H * W * Cout && ((((uintptr_t)ws | (uintptr_t)Y)) & 15) == 0,
+                 "cy_conv3x3_winograd: ws holds %lld floats, the split reduction needs %lld (cy_wino_split_ws_floats), 16-byte aligned",
+                 ws_floats, (long long)S * B * H * W * Cout);
+      a.Cin = Cin / S; a.yslab = (long long)B * H * W * Cout; a.Y = ws;
+    }
+  }
   a.ntiles = (int)tiles;
   int dev = 0, ncu = 0;
   hipError_t he = hipGetDevice(&dev);
@@ -1178,8 +1229,13 @@ extern "C" int cy_conv3x3_winograd(const float* X, const float* U, float* Y, con
   if (rc) return rc;
   if (a.stats != nullptr) wino_conv_kernel<1><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
   else if (out_slope != 1.f) wino_conv_kernel<2><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
-  else wino_conv_kernel<0><<<(unsigned)blocks, 256, lds, (hipStream_t)stream>>>(a);
+  else wino_conv_kernel<0><<<dim3((unsigned)blocks, (unsigned)S), 256, lds, (hipStream_t)stream>>>(a);
   CY_LAUNCH_CHECK("cy_conv3x3_winograd");
+  if (S > 1) {
+    const long long n4 = a.yslab / 4;
+    wino_split_sum_kernel<<<(unsigned)cy_ceil_div(n4, 256), 256, 0, (hipStream_t)stream>>>(ws, Y, S, n4);
+    CY_LAUNCH_CHECK("cy_conv3x3_winograd (split sum)");
+  }
   return 0;
 }
 

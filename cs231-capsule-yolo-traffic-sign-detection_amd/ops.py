@@ -168,9 +168,15 @@ def _winograd(x, weight, bias, stats, transpose, tag, out_slope=1.0):
     u = _empty((query('cy_wino4_packed_floats' if f4 else 'cy_wino_packed_floats', Cg, n),), x)
     call('cy_wino4_pack_weights' if f4 else 'cy_wino_pack_weights', _ptr(weight), _ptr(u), Cout_l, Cin_l, 1 if transpose else 0, st)
     y = _empty((B, H, W_, n), x)
+    # F(2x2,3x3) launches without an epilogue that fill at most half the chip (DarkNet's 13 x 13 input gradients) split their reduction
+    nws = 0 if f4 else query('cy_wino_split_ws_floats', B, H, W_, Cg, n, int(bias is None and stats is None and out_slope == 1.0))
+    ws = _empty((nws,), x) if nws > 0 else None
     with timer.range(('conv_wino4_' if f4 else 'conv_wino_') + ('dgrad/' if transpose else 'fwd/') + tag):
-        call('cy_conv3x3_winograd4' if f4 else 'cy_conv3x3_winograd', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats),
-             float(out_slope), B, H, W_, Cg, n, st)
+        if f4:
+            call('cy_conv3x3_winograd4', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), float(out_slope), B, H, W_, Cg, n, st)
+        else:
+            call('cy_conv3x3_winograd_ws', _ptr(x), _ptr(u), _ptr(y), _ptr(bias), _ptr(stats), float(out_slope), B, H, W_, Cg, n,
+                 _ptr(ws), nws, st)
     return y
 
 

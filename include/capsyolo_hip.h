@@ -162,6 +162,13 @@ long long cy_wino_packed_floats(int Cin, int N);
 int cy_wino_pack_weights(const float* W, float* U, int Cout, int Cin, int transpose, void* stream);
 int cy_conv3x3_winograd(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
                         int B, int H, int W, int Cin, int Cout, void* stream);
+/* The same with an optional workspace: a launch WITHOUT an epilogue (plain = no bias, no statistics, no activation: the input
+ * gradients) whose tiles fill at most half of the CUs (DarkNet's 13 x 13 layers, models.py:196-223: 128 tiles) splits its
+ * reduction channels over up to 4 blocks per tile; the shares' slabs are added in a fixed order.  ws: cy_wino_split_ws_floats
+ * floats (0 = this shape does not split), 16-byte aligned. */
+long long cy_wino_split_ws_floats(int B, int H, int W, int Cin, int Cout, int plain);
+int cy_conv3x3_winograd_ws(const float* X, const float* U, float* Y, const float* bias, double* stats, float out_slope,
+                           int B, int H, int W, int Cin, int Cout, float* ws, long long ws_floats, void* stream);
 /* The same convolution through Winograd F(4x4,3x3) (36 multiplies per 4x4 outputs: 1.78x fewer MFMAs than F(2x2,3x3);
  * fp32 error ~2e-6 relative; replaces the same nn.Conv2d forward / input gradient, models.py:349-351).  Same arguments
  * and meaning as the three functions above; U has its own layout (cy_wino4_packed_floats / cy_wino4_pack_weights). */

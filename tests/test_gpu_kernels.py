@@ -107,6 +107,38 @@ def test_conv_gemm_split_reduction(case, monkeypatch):
     close(dx, dx1, 1e-5, 1e-5)
 
 
+@pytest.mark.parametrize('case', [(16, 512, 13, 1024, 2), (4, 256, 13, 768, 4), (3, 128, 16, 384, 3), (16, 512, 26, 256, 1)])
+def test_conv3x3_winograd_input_gradient_splits_its_reduction(case, monkeypatch):
+    """F(2x2,3x3) launches without an epilogue whose tiles fill at most half of the CUs run several blocks per tile on shares of the
+    reduction channels (cy_conv3x3_winograd_ws / cy_wino_split_ws_floats; round 4): DarkNet's 13 x 13 input gradients (conv_14 /
+    16 / 18: 128 tiles, 2 shares), a four-share and a three-share case, and a shape that must NOT split (26 x 26: 256 tiles).
+    Against torch fp64, against the unsplit launch of the same kernel, bit-identical on repetition; the forward (bias, statistics:
+    an epilogue) never splits."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import query
+    monkeypatch.setattr(ops, 'USE_WINOGRAD4', False)
+    B, Cin, H, Cout, shares = case
+    x = rnd((B, Cin, H, H), 71)
+    w = rnd((Cout, Cin, 3, 3), 72, (1.0 / (Cin * 9)) ** 0.5)
+    xd = x.double().requires_grad_(True)
+    zr = F.conv2d(xd, w.double(), None, padding=1)
+    gz = rnd(tuple(zr.shape), 74)
+    zr.backward(gz.double())
+    gzd = gz.permute(0, 2, 3, 1).contiguous().to(dev())
+    wg = w.to(dev())
+    n = query('cy_wino_split_ws_floats', B, H, H, Cout, Cin, 1)        # (the input gradient reduces over the layer's Cout)
+    assert n == (shares * B * H * H * Cin if shares > 1 else 0), (n, shares)
+    assert query('cy_wino_split_ws_floats', B, H, H, Cin, Cout, 0) == 0
+    dx = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), 3, 1, 1)
+    dx_again = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), 3, 1, 1)
+    assert torch.equal(dx, dx_again)
+    close(dx.permute(0, 3, 1, 2), xd.grad, 1e-4, 1e-4)
+    real_query = ops.query
+    monkeypatch.setattr(ops, 'query', lambda name, *a: 0 if name == 'cy_wino_split_ws_floats' else real_query(name, *a))
+    dx_unsplit = ops.conv_dgrad(gzd, wg, (B, H, H, Cin), 3, 1, 1)
+    close(dx, dx_unsplit, 2e-5, 2e-5)
+
+
 @pytest.mark.parametrize('case', [(2, 128, 16, 256), (1, 8, 10, 64), (3, 64, 37, 40), (2, 256, 18, 128), (2, 32, 15, 10),
                                   (3, 8, 200, 64), (2, 16, 104, 128)])   # > 256 tiles: persistent blocks walk several tiles
 @pytest.mark.parametrize('f4', [False, True])
