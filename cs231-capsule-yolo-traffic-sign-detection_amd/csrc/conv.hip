@@ -699,13 +699,15 @@ __global__ void channel_sum_kernel(const float* __restrict__ dZ, float* __restri
 // of 3.02 rounds costs 4.
 int pick_splits(int tiles, long long M, long long slab_floats) {
   const long long capacity = 512;
-  // keep >= 1024 pixels (32 stages) per split where a split's slab is large (conv_2: 1.2 MB written and read back per split); a layer
-  // with a tiny gradient (CapsuleNet's decoder: K N = 288 .. 1152 floats) is a chain of load latencies, not of work: down to 128
-  // pixels per split (its 8192-pixel layer ran 8 blocks for 0.55 ms of a 2.8 ms step)
-  long long min_px = slab_floats / 64;
-  if (min_px < 128) min_px = 128;
-  if (min_px > 1024) min_px = 1024;
+  // a layer with a tiny gradient (CapsuleNet's decoder: K N = 288 .. 1152 floats) is a chain of load latencies, not of work: down to 128
+  // pixels per split (its 8192-pixel layer ran 8 blocks of 1024 pixels for 0.55 ms of a 2.8 ms step)
+  // (later in round 4: DarkNet's 1x1 layers at 26 x 26 / 13 x 13 -- 8 and 32 output tiles, 10816 / 2704 pixels -- ran 80 / 64 blocks
+  // for 132 / 107 us against 18 us of MFMA time: the floor is 256 pixels (8 pipeline stages) per split, and what bounds the number of
+  // splits of a large gradient is the slab traffic itself: at most 16 M floats of slabs, ~25 us of writes and reads)
+  long long min_px = slab_floats < 8192 ? 128 : 256;
   long long cap = M / min_px;
+  const long long cap_slab = (16ll << 20) / (slab_floats > 0 ? slab_floats : 1);
+  if (cap > cap_slab) cap = cap_slab;
   if (cap < 1) cap = 1;
   long long best = 1;
   double best_util = 0.0;
