@@ -138,7 +138,13 @@ USE_WINOGRAD4_S2 = True  # 4x4 / stride-2 layers: forward on F(4x4,2x2) (winogra
 USE_WINOGRAD4_S2_DGRAD = True      # ... and their input gradient (the same kernel over dY shifted by one pixel, scattered to the four classes)
 WINOGRAD4_S2_MIN_PIXELS = 1 << 16   # this many output pixels on (its 16 x 32-pixel blocks are the F(2x2,2x2) kernel's)
 USE_WINOGRAD4 = True     # ... forward and input gradient on F(4x4,3x3) (winograd4.hip: 1.78x fewer MFMAs) from WINOGRAD4_MIN_PIXELS output pixels on
-WINOGRAD4_MIN_PIXELS = 1 << 18   # 512 output pixels x 64 channels per block: below, its tile grid leaves most of the 256 CUs idle
+WINOGRAD4_MIN_PIXELS = 1 << 17   # 512 output pixels x 64 channels per block: far below, its tile grid leaves most of the 256 CUs idle.  The value is a
+                                 # trade of speed against LeakyReLU kink flips, measured in round 4 (tools/bench_darknet.py 16 <log2 pixels>): darknet_d
+                                 # 8.83 ms per step at 2^18 (round 3's value), 8.69 at 2^17 / 2^16, 8.47 at 2^15, 8.44 at 2^13 -- but F(4x4,3x3) is 2.3e-6
+                                 # from fp64 against 3.6e-7 for F(2x2,3x3), and on the 19-block net every further layer on it flips more pre-activations
+                                 # inside the rounding noise: gradients of the lower blocks against an fp64 run of the same net (128 x 128, three seeds) 5e-3 / 4e-4 /
+                                 # 5e-3 at 2^18 and 2e-2 / 9e-3 / 1.7e-2 at 2^15 (the reference's own fp32 path: 5e-6 / 3e-3 / 8e-3).  2^17 takes the
+                                 # layers where the kernel buys most (>= 131072 output pixels) and leaves the deep small maps on F(2x2,3x3).
 
 
 FUSE_BN_BWD_REDUCE = True  # ... and that block's input-gradient epilogue sums the producer's BatchNorm backward

@@ -7,6 +7,8 @@ import capsyolo_amd
 from capsyolo_amd import loss_fns, models, ops, optim, synth
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+if len(sys.argv) > 2:      # A/B of the F(4x4,.) pixel threshold: python tools/bench_darknet.py 16 <log2 pixels>
+    ops.WINOGRAD4_MIN_PIXELS = 1 << int(sys.argv[2])
 p = types.SimpleNamespace(n_classes=0, n_grid=13, n_boxes=2, dropout=0.0, darknet_input=416, device='cuda', model='darknet_d',
                           l_coord=5.0, l_noobj=0.5)
 torch.manual_seed(0)
