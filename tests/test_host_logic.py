@@ -48,6 +48,23 @@ def test_ctypes_structs_match_header_field_order():
         assert fields == [f[0] for f in struct._fields_], cname
 
 
+def test_split_reduction_plans_without_a_gpu():
+    """The workspace queries of the split reductions are host arithmetic (no launch): cy_conv_gemm_ws_floats plans with 256 CUs when no
+    device answers -- CapsuleNet's primary-capsule convolution at batch 32 (models.py:60-62 fused to 256 -> 128, 8x8 / stride 2 on
+    24 x 24: M = 2592 pixels, 42 tiles of 128 x 64, K = 20736 = 648 K tiles) gets 12 shares; a launch with the statistics epilogue
+    and a launch that fills the chip get none; cy_wino_split_ws_floats never splits a launch with an epilogue."""
+    import ctypes as C
+    a = _lib.ConvGemm(X=1, Wp=1, Y=1, bias=None, stats=None, xs_b=24 * 24 * 256, xs_y=24 * 256, xs_x=256, xs_c=1, B=32, Hi=24, Wi=24, Cin=256,
+                      Ho=9, Wo=9, N=128, TH=8, TW=8, in_stride=2, dy0=0, dx0=0, dstep=1, Hy=9, Wy=9, out_stride=1, out_oy=0, out_ox=0, act=0)
+    assert _lib.query('cy_conv_gemm_ws_floats', C.byref(a)) == 12 * 2592 * 128
+    a.stats = 1                                           # BatchNorm statistics in the epilogue: the finished sums are needed there
+    assert _lib.query('cy_conv_gemm_ws_floats', C.byref(a)) == 0
+    a.stats, a.B = None, 3200                             # 4200 tiles: nothing to split
+    assert _lib.query('cy_conv_gemm_ws_floats', C.byref(a)) == 0
+    assert _lib.query('cy_wino_split_ws_floats', 16, 13, 13, 1024, 512, 0) == 0
+    assert _lib.query('cy_wino_split_ws_floats', 16, 13, 13, 1024, 512, 1) in (0, 2 * 16 * 13 * 13 * 512)   # (0 without a device to count CUs on)
+
+
 def test_product_never_imports_the_oracle_and_has_no_fallback():
     for root, _, files in os.walk(PKG):
         for f in files:
