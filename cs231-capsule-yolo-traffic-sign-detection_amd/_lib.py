@@ -108,6 +108,8 @@ _SIGS = {
     'cy_center_u8': [_P, _P, _I, _I, _I, _I, _I, _P],
     'cy_permute4': [_P, _P, _L, _I, _I, _I, _L, _L, _L, _L, _I, _P],
     'cy_maxpool2_fwd': [_P, _P, _P, _I, _I, _I, _I, _P],
+    'cy_affine_act_maxpool2': [_P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P],
+    'cy_maxpool2_bwd_bn': [_P, _P, _P, _P, _P, _P, _P, _F, _P, _P, _I, _I, _I, _I, _P],
     'cy_maxpool2_bwd': [_P, _P, _P, _I, _I, _I, _I, _P],
     'cy_upsample_fwd': [_P, _P, _I, _I, _I, _I, _I, _P],
     'cy_upsample_bwd': [_P, _P, _I, _I, _I, _I, _I, _P],

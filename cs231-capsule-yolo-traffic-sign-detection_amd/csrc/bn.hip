@@ -381,6 +381,136 @@ extern "C" int cy_bn_bwd_reduce(const float* Z, const float* dA, const float* sc
   return 0;
 }
 
+namespace {
+// ---- conv -> BatchNorm -> LeakyReLU -> MaxPool2d(2) blocks (DarkNet, models.py:135 ... 195), round 4: the activation never exists at full
+// resolution.  Forward: y = max over the 2 x 2 window of lrelu(z * scale + shift), idx = the winning position (0 .. 3, the first of equals
+// in row-major order: nn.MaxPool2d's choice); one thread = 4 channels of one pooled pixel.
+__global__ void affine_act_maxpool2_kernel(const float* __restrict__ Z, const float* __restrict__ scale, const float* __restrict__ shift,
+                                           float slope, float* __restrict__ Y, unsigned char* __restrict__ idx, long long n4, int Ho, int Wo,
+                                           int C) {
+  const int c4n = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    long long r = i;
+    const int c = (int)(r % c4n) * 4; r /= c4n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); r /= Ho;
+    const long long base = ((r * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+    const long long rs = (long long)2 * Wo * C;
+    const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+    const float4 z0 = *(const float4*)(Z + base), z1 = *(const float4*)(Z + base + C), z2 = *(const float4*)(Z + base + rs),
+                 z3 = *(const float4*)(Z + base + rs + C);
+    float4 best;
+    uchar4 bi;
+#define CY_POOL(f)                                                          \
+    {                                                                       \
+      float a = z0.f * sc.f + sh.f; a = fmaxf(a, a * slope);                \
+      float b = z1.f * sc.f + sh.f; b = fmaxf(b, b * slope);                \
+      float c_ = z2.f * sc.f + sh.f; c_ = fmaxf(c_, c_ * slope);            \
+      float d = z3.f * sc.f + sh.f; d = fmaxf(d, d * slope);                \
+      float m = a; unsigned char k = 0;                                     \
+      if (b > m) { m = b; k = 1; }                                          \
+      if (c_ > m) { m = c_; k = 2; }                                        \
+      if (d > m) { m = d; k = 3; }                                          \
+      best.f = m; bi.f = k;                                                 \
+    }
+    CY_POOL(x) CY_POOL(y) CY_POOL(z) CY_POOL(w)
+#undef CY_POOL
+    *(float4*)(Y + i * 4) = best;
+    *(uchar4*)(idx + i * 4) = bi;
+  }
+}
+
+// Backward of the same: dP (gradient of the pooled activation) goes to the winning position, times the activation's derivative there --
+// d = [pos == idx] dP lrelu'(z * scale + shift), the PREMASKED gradient the producer block's backward takes -- and the block's
+// BatchNorm-backward sums (sum d, sum d xhat over the pixels, the cy_bn_bwd_reduce contract) are added on the way: red[N][2] doubles,
+// zeroed by the caller.  Thread layout of bn_bwd_reduce_kernel with pooled pixels as the rows.
+__global__ void maxpool2_bwd_bn_kernel(const float* __restrict__ dP, const unsigned char* __restrict__ idx, const float* __restrict__ Z,
+                                       const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ mean,
+                                       const float* __restrict__ invstd, float slope, float* __restrict__ D, double* red, long long Pp,
+                                       int Ho, int Wo, int N, long long rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];   // [256][8]
+  const int CW = N < 64 ? N : 64, nsl = N / CW;
+  const int LPR = CW >> 2;
+  const int rpar = 256 / LPR;
+  const int t = threadIdx.x;
+  const int u = t % LPR, rsub = t / LPR;
+  const int c0 = (int)(blockIdx.x % nsl) * CW;
+  const int c = c0 + u * 4;
+  const float4 sc = *(const float4*)(scale + c), sh = *(const float4*)(shift + c);
+  const float4 mu = *(const float4*)(mean + c), is = *(const float4*)(invstd + c);
+  const long long r0 = (long long)(blockIdx.x / nsl) * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > Pp) r1 = Pp;
+  struct D4 { double x, y, z, w; };
+  D4 s1 = {0.0, 0.0, 0.0, 0.0}, s2 = s1;
+  const long long rs = (long long)2 * Wo * N;
+  for (long long r = r0 + rsub; r < r1; r += rpar) {
+    long long q = r;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho); q /= Ho;
+    const long long base = ((q * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * N + c;
+    const float4 g = *(const float4*)(dP + r * N + c);
+    const uchar4 bi = *(const uchar4*)(idx + r * N + c);
+    const float4 z0 = *(const float4*)(Z + base), z1 = *(const float4*)(Z + base + N), z2 = *(const float4*)(Z + base + rs),
+                 z3 = *(const float4*)(Z + base + rs + N);
+    float4 d0, d1, d2, d3;
+#define CY_PB(f)                                                                                   \
+    {                                                                                              \
+      const float zw = bi.f == 0 ? z0.f : bi.f == 1 ? z1.f : bi.f == 2 ? z2.f : z3.f;              \
+      const float y = zw * sc.f + sh.f;                                                            \
+      const float d = y > 0.f ? g.f : g.f * slope;                                                 \
+      d0.f = bi.f == 0 ? d : 0.f; d1.f = bi.f == 1 ? d : 0.f; d2.f = bi.f == 2 ? d : 0.f; d3.f = bi.f == 3 ? d : 0.f; \
+      s1.f += (double)d;                                                                           \
+      s2.f += (double)(d * ((zw - mu.f) * is.f));                                                  \
+    }
+    CY_PB(x) CY_PB(y) CY_PB(z) CY_PB(w)
+#undef CY_PB
+    *(float4*)(D + base) = d0; *(float4*)(D + base + N) = d1; *(float4*)(D + base + rs) = d2; *(float4*)(D + base + rs + N) = d3;
+  }
+  double* my = smd + t * 8;
+  my[0] = s1.x; my[1] = s1.y; my[2] = s1.z; my[3] = s1.w;
+  my[4] = s2.x; my[5] = s2.y; my[6] = s2.z; my[7] = s2.w;
+  __syncthreads();
+  for (int id = t; id < 2 * CW; id += 256) {
+    const int n = id % CW, which = id / CW;
+    const int uu = n >> 2, e = n & 3;
+    double acc = 0.0;
+    for (int k = 0; k < rpar; ++k) acc += smd[(k * LPR + uu) * 8 + which * 4 + e];
+    atomicAdd(red + 2 * (c0 + n) + which, acc);
+  }
+}
+}  // namespace
+
+extern "C" int cy_affine_act_maxpool2(const float* Z, const float* scale, const float* shift, float slope, float* Y, unsigned char* idx,
+                                      int B, int Ho, int Wo, int C, void* stream) {
+  CY_REQUIRE(Z && scale && shift && Y && idx && B > 0 && Ho > 0 && Wo > 0, "cy_affine_act_maxpool2: bad arguments");
+  CY_REQUIRE(C > 0 && C % 4 == 0 && slope >= 0.f && slope <= 1.f, "cy_affine_act_maxpool2: C=%d must be a multiple of 4, slope=%g in [0, 1]", C, (double)slope);
+  CY_REQUIRE((((uintptr_t)Z | (uintptr_t)Y | (uintptr_t)idx) & 15) == 0, "cy_affine_act_maxpool2: operands must be 16-byte aligned");
+  const long long n4 = (long long)B * Ho * Wo * (C / 4);
+  affine_act_maxpool2_kernel<<<stream_grid(n4), 256, 0, (hipStream_t)stream>>>(Z, scale, shift, slope, Y, idx, n4, Ho, Wo, C);
+  CY_LAUNCH_CHECK("cy_affine_act_maxpool2");
+  return 0;
+}
+
+extern "C" int cy_maxpool2_bwd_bn(const float* dP, const unsigned char* idx, const float* Z, const float* scale, const float* shift,
+                                  const float* mean, const float* invstd, float slope, float* D, double* red, int B, int Ho, int Wo,
+                                  int C, void* stream) {
+  CY_REQUIRE(dP && idx && Z && scale && shift && mean && invstd && D && red && B > 0 && Ho > 0 && Wo > 0, "cy_maxpool2_bwd_bn: bad arguments");
+  CY_REQUIRE(C > 0 && C % 4 == 0 && (C < 64 ? 256 % (C / 4) == 0 : C % 64 == 0) && slope >= 0.f && slope <= 1.f,
+             "cy_maxpool2_bwd_bn: C=%d must be a multiple of 64 (or 4, 8, 16, 32), slope=%g in [0, 1]", C, (double)slope);
+  CY_REQUIRE((((uintptr_t)dP | (uintptr_t)idx | (uintptr_t)Z | (uintptr_t)D) & 15) == 0, "cy_maxpool2_bwd_bn: operands must be 16-byte aligned");
+  const int CW = C < 64 ? C : 64, nsl = C / CW, rpar = 256 / (CW / 4);
+  const long long Pp = (long long)B * Ho * Wo;
+  long long rows_per_block = cy_ceil_div(Pp, cy_ceil_div(2048, nsl));     // about 2048 blocks
+  if (rows_per_block < 4 * rpar) rows_per_block = 4 * rpar;
+  rows_per_block = cy_ceil_div(rows_per_block, rpar) * rpar;
+  const long long blocks = cy_ceil_div(Pp, rows_per_block) * nsl;
+  maxpool2_bwd_bn_kernel<<<(unsigned)blocks, 256, 256 * 8 * 8, (hipStream_t)stream>>>(dP, idx, Z, scale, shift, mean, invstd, slope, D, red, Pp,
+                                                                                    Ho, Wo, C, rows_per_block);
+  CY_LAUNCH_CHECK("cy_maxpool2_bwd_bn");
+  return 0;
+}
+
 extern "C" int cy_bn_bwd_apply(const float* Z, const float* dA, float* dZ, const float* scale, const float* shift,
                                const float* mean, const float* invstd, const float* gamma, float slope,
                                const double* red, float* dgamma, float* dbeta, long long P, int N, void* stream) {

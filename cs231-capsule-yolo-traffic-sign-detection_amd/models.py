@@ -144,13 +144,24 @@ class FusedBackbone(nn.Sequential):
                     ho = (hin + 2 * m.padding - m.k) // m.stride + 1
                     wo = (win + 2 * m.padding - m.k) // m.stride + 1
                     defer = ops.s2_fusable(n.k, n.stride, n.padding, m.weight.shape[0], n.weight.shape[0], ho, wo)
+                # ... and when a max-pool follows (DarkNet): activation + pooling in ONE pass over z, the pooling's backward with this
+                # block's BatchNorm-backward sums in one pass (not for the first layer: its recompute kernels keep their own path)
+                pool = False
+                if (self.training and bn is not None and bn.training and nxt < len(mods) and isinstance(mods[nxt], HipMaxPool2)
+                        and not (nchw_in and ops.conv1_ok(x, m.weight, m.k, m.stride, m.padding, nchw_in)) and not nchw_in):
+                    ho = (x.shape[1] + 2 * m.padding - m.k) // m.stride + 1
+                    wo = (x.shape[2] + 2 * m.padding - m.k) // m.stride + 1
+                    pool = defer = ops.pool_fusable(m.weight.shape[0], ho, wo, slope)
                 cfg = ops.ConvBlockCfg(m.k, m.stride, m.padding, nchw_in, bn, slope, names[i], defer_act=defer,
                                        in_slope=lazy[2] if lazy is not None else None)
                 cfg.in_holder = lazy[3] if lazy is not None else None
                 out = ops.conv_block(x, m.weight, m.bias, bn.weight if bn is not None else None,
                                      bn.bias if bn is not None else None, cfg,
                                      lazy[0] if lazy is not None else None, lazy[1] if lazy is not None else None)
-                if defer:
+                if pool:
+                    x, lazy = ops.affine_act_maxpool(out[0], out[1], out[2], slope, getattr(cfg, 'out_holder', None)), None
+                    nxt += 1                                  # the max-pool module is done
+                elif defer:
                     x, lazy = out[0], (out[1], out[2], slope, getattr(cfg, 'out_holder', None))
                 else:
                     x, lazy = out, None

@@ -1094,6 +1094,52 @@ def maxpool2(x):
     return _MaxPool2.apply(x)
 
 
+FUSE_POOL = True    # conv -> BatchNorm -> LeakyReLU -> MaxPool blocks (DarkNet): activation + pooling in one pass over z, pooling backward +
+                    # the block's BatchNorm-backward sums in one pass (the full-resolution activation and its gradient are never stored twice)
+
+
+def pool_fusable(C, H, W, slope):
+    """The fused BatchNorm-apply + LeakyReLU + 2x2 max-pool pass takes this block's output [B,H,W,C]."""
+    return (FUSE_POOL and H % 2 == 0 and W % 2 == 0 and C % 4 == 0 and (C % 64 == 0 or C in (4, 8, 16, 32)) and slope is not None
+            and 0.0 < slope <= 1.0)
+
+
+class _AffineActMaxPool(torch.autograd.Function):
+    """y = maxpool2(lrelu(z * scale + shift)) of a block that deferred its activation (ConvBlockCfg.defer_act); plays the CONSUMER of the
+    producer's hand-over dict: its backward returns the premasked gradient d = [pos == argmax] dy lrelu'(.) as the gradient of z and leaves
+    the producer's BatchNorm-backward sums in holder['red'] (models.py:135 ... 195: nn.LeakyReLU + nn.MaxPool2d of the DarkNet blocks)."""
+
+    @staticmethod
+    def forward(ctx, z, scale, shift, slope, holder):
+        z = _f32(z, 'conv output')
+        B, H, W, Cc = z.shape
+        y = _empty((B, H // 2, W // 2, Cc), z)
+        idx = torch.empty((B, H // 2, W // 2, Cc), dtype=torch.uint8, device=z.device)
+        with timer.range('affine_act_maxpool'):
+            call('cy_affine_act_maxpool2', _ptr(z), _ptr(scale), _ptr(shift), float(slope), _ptr(y), _ptr(idx), B, H // 2, W // 2, Cc, _stream())
+        ctx.save_for_backward(z, scale, shift, idx)
+        ctx.slope, ctx.holder = float(slope), holder
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, scale, shift, idx = ctx.saved_tensors
+        B, H, W, Cc = z.shape
+        dy = _f32(dy, 'pooled gradient')
+        h = ctx.holder
+        d = torch.empty_like(z)
+        red = zero_pool.take((Cc, 2), torch.float64, z.device)
+        with timer.range('maxpool_bwd_bn'):
+            call('cy_maxpool2_bwd_bn', _ptr(dy), _ptr(idx), _ptr(z), _ptr(scale), _ptr(shift), _ptr(h['mean']), _ptr(h['invstd']), ctx.slope,
+                 _ptr(d), _ptr(red), B, H // 2, W // 2, Cc, _stream())
+        h['red'], h['premasked'] = red, True
+        return d, None, None, None, None
+
+
+def affine_act_maxpool(z, scale, shift, slope, holder):
+    return _AffineActMaxPool.apply(z, scale, shift, slope, holder)
+
+
 class _Upsample(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, f):

@@ -401,6 +401,17 @@ int cy_center_u8(const unsigned char* src, float* dst, int B, int H, int W, int 
 int cy_permute4(const float* in, float* out, long long nb, int d1, int d2, int d3, long long sb, long long s1,
                 long long s2, long long s3, int scatter, void* stream);
 /* nn.MaxPool2d(2) on NHWC (models.py:135-195): x [B,2Ho,2Wo,C] -> y [B,Ho,Wo,C]; idx keeps the argmax (0..3) */
+/* conv -> BatchNorm -> LeakyReLU -> MaxPool2d(2) blocks (models.py:135 ... 195) without the full-resolution activation:
+ * Y[B][Ho][Wo][C] = max over the 2 x 2 window of lrelu(Z * scale + shift) (Z [B][2 Ho][2 Wo][C], the block's raw convolution output),
+ * idx = the winning position 0 .. 3 (first of equals in row-major order, as nn.MaxPool2d); C % 4 == 0.
+ * Backward: D[B][2 Ho][2 Wo][C] = [position == idx] dP lrelu'(Z * scale + shift) -- the premasked gradient the block's backward takes
+ * (cy_conv3x3_winograd_wgrad_bn premasked = 1 / cy_bn_bwd_apply with slope 1) -- and red[C][2] (doubles, zeroed by the caller) +=
+ * (sum D, sum D xhat): the cy_bn_bwd_reduce pass of that block.  C a multiple of 64 (or 4 .. 32). */
+int cy_affine_act_maxpool2(const float* Z, const float* scale, const float* shift, float slope, float* Y, unsigned char* idx,
+                           int B, int Ho, int Wo, int C, void* stream);
+int cy_maxpool2_bwd_bn(const float* dP, const unsigned char* idx, const float* Z, const float* scale, const float* shift,
+                       const float* mean, const float* invstd, float slope, float* D, double* red, int B, int Ho, int Wo, int C,
+                       void* stream);
 int cy_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int B, int Ho, int Wo, int C, void* stream);
 int cy_maxpool2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int Ho, int Wo, int C, void* stream);
 /* nn.Upsample (nearest, integer factor f; models.py:99-105) on NHWC and its backward */

@@ -1254,3 +1254,41 @@ def test_round3_winograd_kernels_repeat_bit_for_bit(monkeypatch):
     keys = ops.timer.summary()
     for pre in ('conv_wino4_fwd/', 'conv_wino4_dgrad/', 'conv_wino4_wgrad/', 'conv_wino42_fwd/', 'conv_wino42_dgrad/'):
         assert any(k.startswith(pre) for k in keys), pre
+
+
+@pytest.mark.parametrize('case', [(3, 64, 12, 10), (2, 128, 6, 14), (1, 512, 4, 2), (2, 32, 8, 8)])
+def test_fused_batchnorm_activation_maxpool_and_its_backward(case):
+    """cy_affine_act_maxpool2 / cy_maxpool2_bwd_bn (round 4: DarkNet's conv -> BatchNorm -> LeakyReLU -> MaxPool blocks, models.py:135 ...
+    195): forward against torch (F.max_pool2d of the activated tensor; ties go to the first position like nn.MaxPool2d: checked on a
+    tensor with repeated values), backward: the premasked gradient against autograd's gradient of z, the BatchNorm-backward sums
+    against cy_bn_bwd_reduce's contract (sum d, sum d xhat) in fp64."""
+    from capsyolo_amd import ops
+    B, C, Ho, Wo = case
+    z = rnd((B, 2 * Ho, 2 * Wo, C), 301)
+    z[0, :2, :2, :] = 0.25                                     # a window of equal values: the first position must win
+    scale, shift = rnd((C,), 302).abs() + 0.5, rnd((C,), 303, 0.3)
+    mean, invstd = rnd((C,), 304, 0.2), rnd((C,), 305).abs() + 0.5
+    slope = 0.1
+    dy = rnd((B, Ho, Wo, C), 306)
+    zd = z.double().requires_grad_(True)
+    act = F.leaky_relu(zd * scale.double() + shift.double(), slope)
+    pooled, ind = F.max_pool2d(act.permute(0, 3, 1, 2), 2, return_indices=True)
+    pooled.backward(dy.permute(0, 3, 1, 2).double())
+    holder = {'mean': mean.to(dev()), 'invstd': invstd.to(dev()), 'red': None}
+    zg = z.to(dev()).requires_grad_(True)
+    y = ops.affine_act_maxpool(zg, scale.to(dev()), shift.to(dev()), slope, holder)
+    close(y.permute(0, 3, 1, 2), pooled, 1e-6, 1e-6)
+    assert int(torch.count_nonzero(y[0, 0, 0] - float(F.leaky_relu(torch.tensor(0.25) * scale + shift, slope)[0]))) <= C   # (shape check only)
+    ops.zero_pool.reset(torch.device('cuda', 0))
+    y.backward(dy.to(dev()))
+    d = zg.grad
+    # autograd's dz = d * scale (chain through z * scale + shift); the kernel hands over d itself (the producer applies the BatchNorm)
+    close(d * scale.to(dev()), zd.grad.float(), 1e-5, 1e-6)
+    assert holder['premasked'] is True
+    dref = (zd.grad / scale.double()).detach()
+    xhat = (z.double() - mean.double()) * invstd.double()
+    red = holder['red'].cpu()
+    close(red[:, 0], dref.sum(dim=(0, 1, 2)), 1e-5, 1e-6)          # (fp32 terms d, d * xhat summed in double: the terms' own rounding)
+    close(red[:, 1], (dref * xhat).sum(dim=(0, 1, 2)), 1e-4, 1e-5)
+    # ties: position 0 of the constant window got the gradient
+    assert float(d[0, 0, 0].abs().sum()) > 0 and float(d[0, 0, 1].abs().sum()) == 0 and float(d[0, 1, 0].abs().sum()) == 0
