@@ -411,14 +411,19 @@ def secondary(dev, steps=5):
     def fwd0(m, xb, yb):
         sc, rec = m(xb, yb, True)
         return sc, loss_fns.capsule_loss(sc, yb, p, xb, rec)
-    gstep = GraphedStep(net, fwd0, opt, (x, y))
-    dtg, finalg = _timed_steps(lambda: gstep(x, y)[1], 5, 4 * steps)
+    graph_err = None
+    try:
+        gstep = GraphedStep(net, fwd0, opt, (x, y))
+        dtg, finalg = _timed_steps(lambda: gstep(x, y)[1], 5, 4 * steps)
+    except Exception as e:      # (an extra must never cost the line its headline)
+        graph_err, dtg, finalg = '%s: %s' % (type(e).__name__, e), float('nan'), float('nan')
     out['capsule_32_b32_f32'] = {
         'config': {'workload': 'experiments/capsule GTSRB-shaped 32x32, 43 classes, 3 routing iters, batch 32, recon on, fp32 '
                                '(BASELINE configs[0] on the GPU)'},
         'value': round(B / dt, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dt, 3), 'steps': 4 * steps, 'warmup': 5,
         'dtype': 'f32', 'final_loss': round(final, 6),
-        'hip_graph_replay': {'value': round(B / dtg, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dtg, 3), 'steps': 4 * steps,
+        'hip_graph_replay': {'error': graph_err} if graph_err else
+                            {'value': round(B / dtg, 1), 'unit': 'images/s', 'ms_per_step': round(1e3 * dtg, 3), 'steps': 4 * steps,
                              'final_loss': round(finalg, 6), 'note': 'forward + loss + backward + Adam captured once (torch.cuda.graph over '
                              'the C-ABI launches), replayed per step; batch and optimizer scalars through device memory'},
         'kernel_ms_per_step': dict((k, round(ms * cnt / 3, 4)) for k, (cnt, ms) in sorted(kt.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:8])}
@@ -610,14 +615,19 @@ def main():
                                        'centring + NHWC->NCHW on the device (capsyolo_amd/input_pipeline.py)'},
             'kernel_ms': dict((k, round(v[1], 4)) for k, v in sorted(kt.items())),
         }
+        def extra(name, fn):        # an extra that fails is reported as such: it must never cost the line its headline
+            try:
+                line[name] = fn()
+            except Exception as e:
+                line[name] = {'error': '%s: %s' % (type(e).__name__, str(e)[:300])}
         if not args.no_extras:
-            line['roofline_routing_c43'] = routing_c43(dev, B)
-            line['loss_curve_parity'] = loss_curve_parity(dev)
+            extra('roofline_routing_c43', lambda: routing_c43(dev, B))
+            extra('loss_curve_parity', lambda: loss_curve_parity(dev))
             if world == 1:
                 torch.cuda.empty_cache()
-                line['secondary'] = secondary(dev)
+                extra('secondary', lambda: secondary(dev))
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args, g)
+            extra('cpu_baseline', lambda: cpu_baseline(args, g))
         print(json.dumps(line), flush=True)
 
 
