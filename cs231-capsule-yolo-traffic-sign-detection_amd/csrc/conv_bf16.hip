@@ -148,6 +148,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
   asm volatile("" : "+s"(zaddr));
   const u16* zsrc = (const u16*)(uintptr_t)zaddr;
   auto piece = [&](int buf, int j) {
+#ifdef CY_BF_DBG
+    if ((CY_BF_DBG & 1) && j < NA) return;           // timing knock-outs (results are wrong): 1 no A pieces, 2 no B pieces
+    if ((CY_BF_DBG & 2) && j >= NA) return;
+#endif
     unsigned char* Ab = smem_raw + buf * BUF_BYTES + wave * 8 * ROWB;      // this wave's 1 KiB piece of round 0
     if (j < NA) {
       const int iy = iy0[j] + tap_a * a.dstep, ix = ix0[j] + tap_b * a.dstep;
