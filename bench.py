@@ -174,7 +174,7 @@ def loss_curve_parity(dev):
     416 x 416 headline step without a switch (first block: patch-moment statistics + one-pass backward; conv_2: F(4x4,3x3) /
     F(3x3,4x4); conv_3: F(4x4,2x2); conv_4 / conv_5 are small here and take F(2x2,2x2)):
       dw64   64 x 64, n_grid 2, batch 64: WELL-CONDITIONED (the reference's one-ulp twin stays within 1.7e-5 of the range on all 20
-             steps): every step is held to 1e-4 of the curve's range (1e-4 relative on step 0)
+             steps): every step is held to 3 x that band = 5.2e-5 of the curve's range (1e-4 relative on step 0)
       di256  256 x 256, n_grid 8, batch 4: chaotic from step 3 on (Adam's sign-like first steps): strict on steps 0 .. 2, the rest
              counted against 4 sigma of the reference's own spread."""
     import numpy as np
@@ -185,7 +185,7 @@ def loss_curve_parity(dev):
     out = {'against': 'tests/golden/curves_ens.npz (reference runs: unperturbed, 8 x one-ulp, 8 x sixteen-ulp, fp64); rule: |c_k - mean_k| <= '
                       'max(floor_k, 4 max_{j<=k} sigma_j), floor_0 = 1e-4 |mean_0|, floor_k = floor_frac x range; strict on the steps whose '
                       'envelope is <= 2 % of the range', 'steps': 20}
-    for tag, floor_frac in (('dw64', 1e-4), ('di256', 2e-4)):
+    for tag, floor_frac in (('dw64', None), ('di256', 2e-4)):      # None: 3 x the reference's own one-ulp band (5.2e-5 of the range)
         H, gg, B = (int(v) for v in g[tag + '_cfg'][:3])
         env = curve_envelope(g, tag, floor_frac=floor_frac)
         c = hip_curve_default_init(g, tag)

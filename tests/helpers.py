@@ -135,7 +135,8 @@ STRICT_FRAC = 0.02     # a step whose envelope is at most this fraction of the c
 def curve_envelope(g, tag, floor_frac=2e-4, first_rel=1e-4, nsigma=4.0, leave_out=None):
     """Per-step envelope of recipe ``tag`` of tests/golden/curves_ens.npz: mean_k and sigma_k over the
     reference's own runs (the unperturbed run, 8 one-ulp and 8 sixteen-ulp input perturbations), and the bound
-        |c_k - mean_k| <= max(floor_k, nsigma * max_{j <= k} sigma_j),   floor_0 = first_rel * |mean_0|,  floor_k = floor_frac * range.
+        |c_k - mean_k| <= max(floor_k, nsigma * max_{j <= k} sigma_j),   floor_0 = first_rel * |mean_0|,  floor_k = floor_frac * range
+    (floor_frac None: 3 x the largest one-ulp deviation of the ensemble, as a fraction of the range -- dw64: 5.2e-5).
     On the chaotic recipes (di96, di256) sigma_k passes the floor at step 1 .. 2 and the envelope then states the reference's own
     spread; on the well-conditioned recipe (dw64: sigma_k <= 1.3e-5 of the range on all 20 steps) the floor is the bound on every
     step.  Why 4 sigma over the running maximum and not 3 sigma_k: with 17 members and 20 steps a per-step 3 sigma test rejects 6 of
@@ -149,9 +150,11 @@ def curve_envelope(g, tag, floor_frac=2e-4, first_rel=1e-4, nsigma=4.0, leave_ou
         members = np.delete(members, leave_out, 0)
     span = float(base.max() - base.min())
     mean, sigma = members.mean(0), members.std(0, ddof=1)
+    one_ulp_band = np.abs(np.asarray(g[tag + '_ens1'], dtype=np.float64) - base).max(0)
+    if floor_frac is None:                # the well-conditioned recipe: 3 x the reference's own one-ulp band
+        floor_frac = 3.0 * float(one_ulp_band.max()) / span
     floor = np.full(base.shape, floor_frac * span)
     floor[0] = first_rel * abs(mean[0])
-    one_ulp_band = np.abs(np.asarray(g[tag + '_ens1'], dtype=np.float64) - base).max(0)
     bound = np.maximum(floor, nsigma * np.maximum.accumulate(sigma))
     return {'base': base, 'mean': mean, 'sigma': sigma, 'floor': floor, 'bound': bound, 'strict': bound <= STRICT_FRAC * span,
             'gross': np.maximum(floor, 2 * nsigma * np.maximum.accumulate(sigma)),

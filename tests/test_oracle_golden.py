@@ -427,7 +427,7 @@ def test_curve_ensembles_are_consistent_and_the_envelope_can_fail():
     """tests/golden/curves_ens.npz (make_golden.py curves_ens): per recipe the reference's unperturbed curve, its fp64 run and 8 + 8
     runs with every input element moved by 1 / 16 ulps.  Pinned here: the di96 / di256 base curves ARE those of curves_init.npz; the
     well-conditioned recipe (dw64) keeps its one-ulp band under 0.5 % of the range on all 20 steps (in fact 2e-5)
-    and falls monotonically; the envelope holds (nearly all of) its own members and rejects an offset of 3e-4 of the range on one
+    and falls monotonically; the envelope holds (nearly all of) its own members and rejects an offset of 1e-4 of the range on one
     step or a relative 3e-4 on the first step; no run of the reference itself fails its leave-one-out envelope."""
     from helpers import curve_envelope, curve_in_envelope
     g, gi = load_golden('curves_ens'), load_golden('curves_init')
@@ -448,13 +448,14 @@ def test_curve_ensembles_are_consistent_and_the_envelope_can_fail():
                                   if not (np.abs(full['members'][m] - e['mean']) <= np.maximum(e['floor'], 3 * e['sigma'])).all())
         assert three_sigma_rejects >= (4 if tag == 'di96' else 0)                # (what the plain rule does to the reference's own runs)
         assert (full['bound'][1:3] <= 1e-2 * full['span']).all()                # the early steps are tight on every recipe
-    env = curve_envelope(g, 'dw64', floor_frac=1e-4)
+    env = curve_envelope(g, 'dw64', floor_frac=None)
+    assert abs(env['floor'][1] / env['span'] - 5.2e-5) < 2e-6
     assert (env['one_ulp_band'] <= 5e-3 * env['span']).all() and env['one_ulp_band'].max() <= 3e-5 * env['span']
     assert (np.diff(env['base']) < 0).all()
     assert (3 * env['sigma'] <= env['floor'])[1:].all()                          # dw64: the floor is the bound on every step
     assert curve_in_envelope(env['curve64'], env)[1].all()                       # the reference in double lies inside
     bad = env['base'].copy()
-    bad[7] += 3e-4 * env['span']
+    bad[7] += 1e-4 * env['span']
     assert not curve_in_envelope(bad, env)[1][7] and curve_in_envelope(bad, env)[1].sum() == 19
     bad = env['base'].copy()
     bad[0] *= 1 + 3e-4

@@ -21,7 +21,7 @@ np.set_printoptions(precision=2, linewidth=260)
 
 
 def report(label, tag, curve):
-    env = curve_envelope(g, tag)
+    env = curve_envelope(g, tag, floor_frac=None if tag == 'dw64' else 2e-4)
     dev, ok = curve_in_envelope(curve, env)
     print('%-44s %s: %2d/20 inside; dev/range %s' % (label, tag, int(ok.sum()), np.array2string(dev / env['span'], formatter={'float_kind': lambda v: '%.1e' % v})))
     print('%-44s      bound/range %s' % ('', np.array2string(env['bound'] / env['span'], formatter={'float_kind': lambda v: '%.1e' % v})))
