@@ -187,6 +187,49 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ dy, const unsigned
   }
 }
 
+// the same with 4 channels per thread (C % 4 == 0, 16-byte aligned tensors): DarkNet's first block is pooled at 416 x 416 x 32 -- the
+// one-element-per-thread kernels above ran its 88 M elements at 97 / 86 us
+__global__ void maxpool2_fwd4_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
+                                     long long n4, int Ho, int Wo, int C) {
+  const int c4n = C >> 2;
+  CY_GRID_STRIDE(i, n4) {
+    long long r = i;
+    const int c = (int)(r % c4n) * 4; r /= c4n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); r /= Ho;
+    const long long base = ((r * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+    const long long rs = (long long)2 * Wo * C;
+    const float4 a = *(const float4*)(x + base), b = *(const float4*)(x + base + C), c_ = *(const float4*)(x + base + rs),
+                 d = *(const float4*)(x + base + rs + C);
+    float4 best = a;
+    uchar4 bi = {0, 0, 0, 0};
+#define CY_MP(f) { if (b.f > best.f) { best.f = b.f; bi.f = 1; } if (c_.f > best.f) { best.f = c_.f; bi.f = 2; } if (d.f > best.f) { best.f = d.f; bi.f = 3; } }
+    CY_MP(x) CY_MP(y) CY_MP(z) CY_MP(w)
+#undef CY_MP
+    *(float4*)(y + i * 4) = best;
+    *(uchar4*)(idx + i * 4) = bi;
+  }
+}
+__global__ void maxpool2_bwd4_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx, float* __restrict__ dx,
+                                     long long n4, int Ho, int Wo, int C) {
+  const int c4n = C >> 2;
+  CY_GRID_STRIDE(i, n4) {
+    long long r = i;
+    const int c = (int)(r % c4n) * 4; r /= c4n;
+    const int ox = (int)(r % Wo); r /= Wo;
+    const int oy = (int)(r % Ho); r /= Ho;
+    const long long base = ((r * (2 * Ho) + 2 * oy) * (2 * Wo) + 2 * ox) * C + c;
+    const long long rs = (long long)2 * Wo * C;
+    const float4 g = *(const float4*)(dy + i * 4);
+    const uchar4 bi = *(const uchar4*)(idx + i * 4);
+    float4 d0, d1, d2, d3;
+#define CY_MB(f) { d0.f = bi.f == 0 ? g.f : 0.f; d1.f = bi.f == 1 ? g.f : 0.f; d2.f = bi.f == 2 ? g.f : 0.f; d3.f = bi.f == 3 ? g.f : 0.f; }
+    CY_MB(x) CY_MB(y) CY_MB(z) CY_MB(w)
+#undef CY_MB
+    *(float4*)(dx + base) = d0; *(float4*)(dx + base + C) = d1; *(float4*)(dx + base + rs) = d2; *(float4*)(dx + base + rs + C) = d3;
+  }
+}
+
 // nearest-neighbour upsample by an integer factor f, NHWC
 __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long long n, int Hi, int Wi, int C,
                                     int f) {
@@ -304,14 +347,20 @@ extern "C" int cy_permute4(const float* in, float* out, long long nb, int d1, in
 extern "C" int cy_maxpool2_fwd(const float* x, float* y, unsigned char* idx, int B, int Ho, int Wo, int C, void* stream) {
   CY_REQUIRE(x && y && idx && B > 0 && Ho > 0 && Wo > 0 && C > 0, "cy_maxpool2_fwd: bad arguments");
   const long long n = (long long)B * Ho * Wo * C;
-  maxpool2_fwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(x, y, idx, n, Ho, Wo, C);
+  if (C % 4 == 0 && (((uintptr_t)x | (uintptr_t)y | (uintptr_t)idx) & 15) == 0)
+    maxpool2_fwd4_kernel<<<grid_for(n / 4), 256, 0, CY_S>>>(x, y, idx, n / 4, Ho, Wo, C);
+  else
+    maxpool2_fwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(x, y, idx, n, Ho, Wo, C);
   CY_LAUNCH_CHECK("cy_maxpool2_fwd");
   return 0;
 }
 extern "C" int cy_maxpool2_bwd(const float* dy, const unsigned char* idx, float* dx, int B, int Ho, int Wo, int C, void* stream) {
   CY_REQUIRE(dy && dx && idx && B > 0 && Ho > 0 && Wo > 0 && C > 0, "cy_maxpool2_bwd: bad arguments");
   const long long n = (long long)B * Ho * Wo * C;
-  maxpool2_bwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(dy, idx, dx, n, Ho, Wo, C);
+  if (C % 4 == 0 && (((uintptr_t)dy | (uintptr_t)dx | (uintptr_t)idx) & 15) == 0)
+    maxpool2_bwd4_kernel<<<grid_for(n / 4), 256, 0, CY_S>>>(dy, idx, dx, n / 4, Ho, Wo, C);
+  else
+    maxpool2_bwd_kernel<<<grid_for(n), 256, 0, CY_S>>>(dy, idx, dx, n, Ho, Wo, C);
   CY_LAUNCH_CHECK("cy_maxpool2_bwd");
   return 0;
 }

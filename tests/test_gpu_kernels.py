@@ -886,6 +886,17 @@ def test_misc_ops():
     (y * G.permute(0, 2, 3, 1).contiguous().to(dev())).sum().backward()
     close(y.permute(0, 3, 1, 2), F.max_pool2d(x, 2), 0, 0)
     close(xh.grad.permute(0, 3, 1, 2), xr.grad, 1e-6)
+    # ... and with a multiple of 4 channels (four channels per thread), incl. a window of equal values (the first position wins)
+    x4 = rnd((3, 32, 10, 12), 54)
+    x4[0, :, :2, :2] = 0.5
+    x4h = x4.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
+    x4r = x4.double().requires_grad_(True)
+    G4 = rnd((3, 32, 5, 6), 55)
+    (F.max_pool2d(x4r, 2) * G4.double()).sum().backward()
+    y4 = ops.maxpool2(x4h)
+    (y4 * G4.permute(0, 2, 3, 1).contiguous().to(dev())).sum().backward()
+    close(y4.permute(0, 3, 1, 2), F.max_pool2d(x4, 2), 0, 0)
+    close(x4h.grad.permute(0, 3, 1, 2), x4r.grad, 1e-6)
     # upsample
     xh2 = x.permute(0, 2, 3, 1).contiguous().to(dev()).requires_grad_(True)
     xr2 = x.double().requires_grad_(True)
