@@ -1,3 +1,6 @@
+"""One-ulp conditioning of a darkcapsule training recipe on the REFERENCE (build container only: imports /root/reference):
+20-step Adam curve from the default initialisation and the spread of runs whose inputs are moved by one ulp.
+    python tools/probe/curve_conditioning.py H n_grid batch seed lr steps members"""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/reference'); sys.dont_write_bytecode=True
