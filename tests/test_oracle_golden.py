@@ -482,3 +482,19 @@ def test_oracle_curve_inside_the_ensemble_envelope():
         curve.append(loss.item())
     v = envelope_verdict(curve, curve_envelope(g, 'di96'))
     assert v['ok'] and v['strict_ok'], (v['steps_within_envelope'], v['dev'].tolist())
+
+
+def test_darknet_curve_ensemble_is_consistent():
+    """tests/golden/curves_ens_dn.npz (make_golden.py curves_ens_dn): the same leave-one-out property for the DarkNet recipe, and the
+    recipe's conditioning as the fixture documents it (twins within 2 % of the range on every step at lr 1e-4)."""
+    from helpers import DARKNET_RULE, curve_envelope, curve_in_envelope
+    g = load_golden('curves_ens_dn')
+    full = curve_envelope(g, 'dn64', **DARKNET_RULE)
+    assert g['dn64_ens1'].shape == (8, 20) and g['dn64_ens16'].shape == (8, 20) and float(g['dn64_lr']) == 1e-4
+    for m in range(17):
+        dev, ok = curve_in_envelope(full['members'][m], curve_envelope(g, 'dn64', leave_out=m, **DARKNET_RULE))
+        assert ok.all(), (m, np.nonzero(~ok)[0].tolist())
+    assert curve_in_envelope(full['curve64'], full)[1].all()
+    assert (full['one_ulp_band'] <= 2e-2 * full['span']).all()
+    assert full['base'][-1] < 0.05 * full['base'][0]             # it trains: 5.85 -> 0.07
+    assert int(full['strict'].sum()) >= 10 and full['strict'][:3].all() and full['strict'][-5:].all()   # tight at both ends, 2 .. 3 % in the transient
