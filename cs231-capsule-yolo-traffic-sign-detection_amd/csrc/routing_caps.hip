@@ -27,7 +27,11 @@ namespace {
 // ([t - 1][row][i][2][C]): this kernel then recomputes neither u_hat (a pass over W_i) nor the logits and the softmax (two
 // dot products over Dout and three wavefront reductions per iteration) -- 250 instead of 560 vector instructions per (row, i).
 constexpr int CDB_TMAX = 4;                         // iterations t >= 1 whose couplings a lane prefetches (n_iter <= 5)
-template <int DOUT, int G, bool SAVED>
+// NTT: the number of routing iterations as a compile-time constant (3: every head of the reference's models), 0 = read from the arguments.
+// With it the loops over the row's vectors and over the iterations unroll, their 64-bit offsets become loop invariants and the
+// selects of the saved couplings disappear: the row loop of the DarkCapsuleNet3 head issued 495 scalar instructions per (row, i)
+// next to 430 vector ones -- from ONE wave per SIMD, where every instruction of either kind takes an issue slot of ~4 cycles.
+template <int DOUT, int G, bool SAVED, int NTT>
 __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a, const float* __restrict__ cdb, int rows_per_chunk,
                                                              int nbuf) {
   constexpr int dbg = CY_B2_DBG;                    // developer knob (compile time: a uniform branch per use cost ~40 cycles each in this one-wave-per-SIMD loop)
@@ -36,7 +40,7 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int C = a.C, N = a.N, R = a.R, NT = a.n_iter;
+  const int C = a.C, N = a.N, R = a.R, NT = NTT > 0 ? NTT : a.n_iter;
   const int NV = 2 * NT - 1;                        // vectors per row: ds^0, (V_t, ds^t) for t = 1 .. T-1
   const int i = blockIdx.x * G + wave;
   const bool iv = i < N;
@@ -85,19 +89,42 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
   // aligned 16-byte pieces that cover it, so that its first float lands `offset & 3` floats into its image
   // (one wave-instruction moves 1 KiB; 4-byte pieces would need four times the DMA instructions, and those, ~100
   // cycles each per CU, were what bounded the first version of this kernel)
-  auto vec_off = [&](int v, int row) -> long long {  // offset of vector v of `row` in the workspace, in floats
+  // (roff = row * CD travels as a running uniform value: recomputed per vector and use, the 64-bit products were a quarter of the
+  // row loop's scalar instructions)
+  auto vec_off = [&](int v, long long roff) -> long long {  // offset of vector v of the row at `roff` in the workspace, in floats
     const int tt = (v + 1) >> 1;                    // v = 0: ds^0; v = 2t-1: V_t; v = 2t: ds^t
-    return ((v & 1) ? vall0 : 0) + (long long)tt * plane + (long long)row * CD;
+    return ((v & 1) ? vall0 : 0) + (long long)tt * plane + roff;
   };
-  auto stage_row = [&](int row, int buf) {
+  // Pieces per vector and the lane's source offset inside a vector do not depend on the row: an unpadded vector is copied as the
+  // vstr / 4 pieces from its aligned start (>= what any alignment needs; the image has room for exactly these), so the lane
+  // predicate, the divisions and -- for the heads of the reference's models, whose vectors fit ONE round of the block's lanes --
+  // the whole loop structure leave the row loop (they were 175 of its instructions per row).
+  constexpr int P5 = DOUT / 4 + 1;
+  const int np = PADV ? C * P5 : (vstr >> 2);
+  const bool one_round = np <= 64 * G;              // uniform
+  const bool mine = t < np;
+  int lsrc = 4 * t;                                 // floats from the vector's (aligned) start
+  if constexpr (PADV) { const int j = t / P5, o4 = t - j * P5; lsrc = o4 < DOUT / 4 ? j * DOUT + 4 * o4 : 0; }
+  auto stage_row = [&](long long roff, int buf) {
     float* dst = rowbuf + buf * rowstride;
+    if (one_round) {
+      if (mine) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          const long long off = vec_off(v, roff);
+          const float* srcv = a.ws + (PADV ? off : (off & ~3ll));       // (padded: 16-byte aligned, C * Dout is a multiple of 4)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcv + lsrc),
+                                           (__attribute__((address_space(3))) void*)(dst + v * vstr + 4 * (wave * 64)), 16, 0, 0);
+        }
+      }
+      return;
+    }
     if constexpr (PADV) {
-      constexpr int P5 = DOUT / 4 + 1;
       for (int v = 0; v < NV; ++v) {
-        const float* srcv = a.ws + vec_off(v, row);            // 16-byte aligned: C * Dout is a multiple of 4
-        for (int base = 0; base < C * P5; base += 64 * G) {
+        const float* srcv = a.ws + vec_off(v, roff);
+        for (int base = 0; base < np; base += 64 * G) {
           const int q = base + t, j = q / P5, o4 = q - j * P5;
-          if (q < C * P5)
+          if (q < np)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(o4 < DOUT / 4 ? srcv + j * DOUT + 4 * o4 : srcv),
                                              (__attribute__((address_space(3))) void*)(dst + v * vstr + 4 * (base + wave * 64)), 16, 0, 0);
         }
@@ -105,37 +132,54 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
       return;
     }
     for (int v = 0; v < NV; ++v) {
-      const long long off = vec_off(v, row);
-      const float* srcv = a.ws + (off & ~3ll);
-      const int nf4 = (int)(((off & 3) + CD + 3) >> 2);
-      for (int base = 0; base < nf4; base += 64 * G) {
-        if (base + t < nf4)
+      const float* srcv = a.ws + (vec_off(v, roff) & ~3ll);
+      for (int base = 0; base < np; base += 64 * G) {
+        if (base + t < np)
           __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcv + 4 * (base + t)),
                                            (__attribute__((address_space(3))) void*)(dst + v * vstr + 4 * (base + wave * 64)), 16, 0, 0);
       }
     }
   };
-  if (r0 < r1) stage_row(r0, 0);
+  // uniform running state of the NEXT row to stage / prefetch: its row * CD, its offset in u (the cell gather's division pair is done
+  // once: rows are cell-major, row = cell * B + image), its row * N * 2 * C in the saved couplings
+  const int ii = iv ? i : 0;
+  long long roff_n = (long long)r0 * CD;
+  long long uoff_n = u_offset_g(r0, ii, N, a.gather_g, a.gather_B);
+  int ub_n = a.gather_g ? r0 % a.gather_B : 0;
+  const long long ustep = a.gather_g ? 16ll * a.gather_g * a.gather_g * 256 : (long long)N * 8;
+  const long long uwrap = a.gather_g ? 4ll * 256 - (long long)a.gather_B * ustep : 0;
+  const long long cstep = (long long)N * 2 * C;
+  long long crow_n = (long long)r0 * cstep;
+  auto advance_next = [&]() {
+    roff_n += CD; crow_n += cstep; uoff_n += ustep;
+    if (a.gather_g && ++ub_n == a.gather_B) { ub_n = 0; uoff_n += uwrap; }
+  };
+  if (r0 < r1) stage_row(roff_n, 0);
   f32x4 un0, un1;                                   // u of the next row (prefetched)
-  auto load_u = [&](int row) {
-    const f32x4* p = (const f32x4*)(a.u + u_offset_g(row, iv ? i : 0, N, a.gather_g, a.gather_B));
+  auto load_u = [&](long long uoff) {
+    const f32x4* p = (const f32x4*)(a.u + uoff);
     un0 = p[0];
     un1 = p[1];
   };
-  if (r0 < r1) load_u(r0);
-  float ccn[CDB_TMAX], dbn[CDB_TMAX];               // SAVED: c^t, db^t of the next row (prefetched like u)
-  auto load_cdb = [&](int row) {
+  if (r0 < r1) load_u(uoff_n);
+  float ccn[CDB_TMAX] = {0.f, 0.f, 0.f, 0.f}, dbn[CDB_TMAX] = {0.f, 0.f, 0.f, 0.f};   // SAVED: c^t, db^t of the next row (prefetched like u)
+  static_assert(CDB_TMAX == 4, "initialisers above");
+  const float* cdb_i = SAVED ? cdb + (long long)ii * 2 * C + jl : nullptr;
+  auto load_cdb = [&](long long crow) {
     if constexpr (SAVED) {
 #pragma unroll
       for (int tt = 0; tt < CDB_TMAX; ++tt) {
-        const int tq = tt < NT - 1 ? tt : NT - 2;     // (slots past the last iteration re-read it: no branch; never used)
-        const float* q = cdb + ((((long long)tq * R + row) * N + (iv ? i : 0)) * 2) * C + jl;
+        if (NTT > 0 && tt >= NTT - 1) continue;       // (compile-time iteration count: no slots past the last iteration)
+        const int tq = tt < NT - 1 ? tt : NT - 2;     // (run-time count: slots past the last iteration re-read it: no branch; never used)
+        const float* q = cdb_i + (long long)tq * R * cstep + crow;
         ccn[tt] = q[0];
         dbn[tt] = q[C];
       }
     }
   };
-  if (r0 < r1) load_cdb(r0);
+  if (r0 < r1) load_cdb(crow_n);
+  long long roff_c = roff_n, uoff_c = uoff_n;       // ... and of the row being computed
+  advance_next();
 
   f32x2 dw[8][HP];
 #pragma unroll
@@ -162,16 +206,15 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
     // end-of-row wait for the next row's data would otherwise sit out its whole round trip
     if (iv && lane < 8 && du_off_prev >= 0 && !(dbg & 2)) a.du[du_off_prev + lane] = du_prev;
     float uv[8] = {un0[0], un0[1], un0[2], un0[3], un1[0], un1[1], un1[2], un1[3]};
-    const long long uoff = u_offset_g(row, iv ? i : 0, N, a.gather_g, a.gather_B);
     float ccur[CDB_TMAX], dbcur[CDB_TMAX];
     if constexpr (SAVED) {
 #pragma unroll
       for (int tt = 0; tt < CDB_TMAX; ++tt) { ccur[tt] = jv ? ccn[tt] : 0.f; dbcur[tt] = jv ? dbn[tt] : 0.f; }   // lanes past C: c = db = 0
     }
     if (row + 1 < r1) {
-      if (nbuf == 2 && !(dbg & 1)) stage_row(row + 1, cur ^ 1);
-      if (!(dbg & 16)) load_u(row + 1);
-      load_cdb(row + 1);
+      if (nbuf == 2 && !(dbg & 1)) stage_row(roff_n, cur ^ 1);
+      if (!(dbg & 16)) load_u(uoff_n);
+      load_cdb(crow_n);
     }
     const float* rb = rowbuf + cur * rowstride + jl * CS;      // vector v of this lane's capsule: rb + v * vstr (+ its offset & 3 when unpadded)
     // ---- u_hat = u W_ij (pairs of output components)
@@ -183,31 +226,34 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 #pragma unroll
       for (int p = 0; p < PF; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[p]) : "v"(wa), "n"(16 * p));
 #pragma unroll
-      for (int q = 0; q < DD4; ++q) {
-        const int younger = (q + PF <= DD4 ? PF : DD4 - q) - 1;
-        f32x4& w = wq[q % PF];
+      for (int q = 0; q < DD4; q += 2) {              // two reads per tied wait (routing_rows.hip: a wait and its s_nop pad are issue slots)
+        const int younger = (q + PF <= DD4 ? PF : DD4 - q) - 2;
+        f32x4& w0 = wq[q % PF];
+        f32x4& w1 = wq[(q + 1) % PF];
         switch (younger) {
-          case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w)); break;
-          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w)); break;
-          case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w)); break;
-          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w)); break;
+          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
+          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
+        for (int e = 0; e < 4; ++e) {
           const int f = 4 * q + 2 * e, d = f / DP, h = (f % DP) / 2;
-          uh[h] = f32x2{w[2 * e], w[2 * e + 1]} * uv[d] + uh[h];
+          const f32x4& w = e < 2 ? w0 : w1;
+          uh[h] = f32x2{w[2 * (e & 1)], w[2 * (e & 1) + 1]} * uv[d] + uh[h];
         }
-        if (q + PF < DD4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(wa), "n"(16 * (q + PF)));
+        if (q + PF < DD4) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * (q + PF)));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * (q + PF + 1)));
+        }
       }
     }
     // ---- du_hat = ds^0 / C + sum_t (c^t ds^t + db^t V_t); V_t and ds^t are streamed from LDS twice (dots, then the
     // update) instead of being held: dW owns the registers
     f32x2 duh[HP];
 #pragma unroll
-    for (int h = 0; h < HP; ++h) duh[h] = ldpair(rb + (PADV ? 0 : (int)(vec_off(0, row) & 3)), h) * (jv ? invC : 0.f);    // lanes past C read capsule 0, scaled by 0
+    for (int h = 0; h < HP; ++h) duh[h] = ldpair(rb + (PADV ? 0 : (int)(vec_off(0, roff_c) & 3)), h) * (jv ? invC : 0.f);    // lanes past C read capsule 0, scaled by 0
     auto t_body = [&](int it) {
-      const float* vp = rb + (2 * it - 1) * vstr + (PADV ? 0 : (int)(vec_off(2 * it - 1, row) & 3));
-      const float* dp = rb + (2 * it) * vstr + (PADV ? 0 : (int)(vec_off(2 * it, row) & 3));
+      const float* vp = rb + (2 * it - 1) * vstr + (PADV ? 0 : (int)(vec_off(2 * it - 1, roff_c) & 3));
+      const float* dp = rb + (2 * it) * vstr + (PADV ? 0 : (int)(vec_off(2 * it, roff_c) & 3));
       // all pairs of V_t and ds^t with ONE wait (inline asm: hipcc would wait behind every read)
       const unsigned va = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)vp;
       const unsigned da = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)dp;
@@ -242,8 +288,11 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 #pragma unroll
         for (int tt = 0; tt < CDB_TMAX; ++tt)
           if (tt == it - 1) { c = ccur[tt]; db = dbcur[tt]; }     // (uniform selects: `it` is a scalar)
+        // two passes: a packed fp32 operation right behind the one it depends on costs a wait state (hipcc pads with s_nop, an issue slot)
 #pragma unroll
-        for (int h = 0; h < HP; ++h) duh[h] = dst[h] * c + (Vt[h] * db + duh[h]);
+        for (int h = 0; h < HP; ++h) duh[h] = Vt[h] * db + duh[h];
+#pragma unroll
+        for (int h = 0; h < HP; ++h) duh[h] = dst[h] * c + duh[h];
         return;
       }
       f32x2 bb = {0.f, 0.f}, dd = {0.f, 0.f};
@@ -270,9 +319,12 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
       const float dot = wave_allsum(c * dc);
       const float db = c * (dc - dot);
 #pragma unroll
-      for (int h = 0; h < HP; ++h) duh[h] = dst[h] * c + (Vt[h] * db + duh[h]);     // c = db = 0 on lanes past C
-        };
-    for (int it = 1; it < ((dbg & 8) ? 1 : NT); ++it) t_body(it);     // (unrolling it for the saved couplings measured no faster)
+      for (int h = 0; h < HP; ++h) duh[h] = Vt[h] * db + duh[h];                    // c = db = 0 on lanes past C
+#pragma unroll
+      for (int h = 0; h < HP; ++h) duh[h] = dst[h] * c + duh[h];
+    };
+#pragma unroll
+    for (int it = 1; it < ((dbg & 8) ? 1 : NT); ++it) t_body(it);
     // ---- du_i[d] = sum_j sum_o W[j][d][o] du_hat_j[o];  dW_ij[d][o] += u[d] du_hat_j[o]
     float p[8];
     {
@@ -280,24 +332,31 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 #pragma unroll
       for (int d = 0; d < 8; ++d) acc[d] = f32x2{0.f, 0.f};
       f32x4 wq[PF];
+      // read order: float4 q of the image's first half (d = 0..3), then its counterpart of the second half (d + 4), ...: the two packed
+      // FMAs of one float4 feed the SAME accumulator as a rule, and back to back the second one waits a state (an s_nop issue slot each)
+      static_assert(DD4 % 2 == 0, "the W image splits into two halves of whole float4");
+      auto qord = [](int k) { return (k & 1) ? DD4 / 2 + (k >> 1) : (k >> 1); };
 #pragma unroll
-      for (int pq = 0; pq < PF; ++pq) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[pq]) : "v"(wa), "n"(16 * pq));
+      for (int pq = 0; pq < PF; ++pq) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[pq]) : "v"(wa), "n"(16 * qord(pq)));
 #pragma unroll
-      for (int q = 0; q < DD4; ++q) {
-        const int younger = (q + PF <= DD4 ? PF : DD4 - q) - 1;
-        f32x4& w = wq[q % PF];
+      for (int k = 0; k < DD4; k += 2) {
+        f32x4& w0 = wq[k % PF];
+        f32x4& w1 = wq[(k + 1) % PF];
+        const int younger = (k + PF <= DD4 ? PF : DD4 - k) - 2;    // reads younger than w1
         switch (younger) {
-          case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w)); break;
-          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w)); break;
-          case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w)); break;
-          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w)); break;
+          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
+          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
         }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-          const int f = 4 * q + 2 * e, d = f / DP, h = (f % DP) / 2;
-          acc[d] = f32x2{w[2 * e], w[2 * e + 1]} * duh[h] + acc[d];
+          const int f0 = 4 * qord(k) + 2 * e, f1 = 4 * qord(k + 1) + 2 * e;
+          acc[f0 / DP] = f32x2{w0[2 * e], w0[2 * e + 1]} * duh[(f0 % DP) / 2] + acc[f0 / DP];
+          acc[f1 / DP] = f32x2{w1[2 * e], w1[2 * e + 1]} * duh[(f1 % DP) / 2] + acc[f1 / DP];
         }
-        if (q + PF < DD4) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(wa), "n"(16 * (q + PF)));
+        if (k + PF < DD4) {
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * qord(k + PF < DD4 ? k + PF : 0)));
+          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * qord(k + PF + 1 < DD4 ? k + PF + 1 : 0)));
+        }
       }
 #pragma unroll
       for (int d = 0; d < 8; ++d) p[d] = acc[d][0] + acc[d][1];
@@ -329,12 +388,14 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
       tot = swap_add32(swap_add16(tot));
       du_prev = tot;
     }
-    du_off_prev = uoff;
+    du_off_prev = uoff_c;
+    roff_c = roff_n; uoff_c = uoff_n;               // the next row becomes the current one
+    advance_next();
 
     __builtin_amdgcn_s_waitcnt(0x0F70);             // next row's vectors (LDS-DMA) and u have landed
     __syncthreads();                                // ... for every wave; and every wave is done with this row's image
     if (nbuf == 1 && row + 1 < r1 && !(dbg & 1)) {
-      stage_row(row + 1, 0);
+      stage_row(roff_c, 0);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
@@ -364,16 +425,15 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 template <int DOUT, int G>
 int launch_g(const cy_routing_bwd_t* a, const float* cdb, int chunks, int rpc, int nbuf, size_t lds, hipStream_t s) {
   const dim3 grid((a->N + G - 1) / G, chunks);
-  if (cdb != nullptr && a->n_iter - 1 <= CDB_TMAX && G <= 4) {    // (six waves share four SIMDs: 256 registers, the variant spills)
-    int rc = cy_allow_lds(caps_bwd_kernel<DOUT, G, true>, lds);
+  auto go = [&](auto kernel, const float* c) -> int {
+    int rc = cy_allow_lds(kernel, lds);
     if (rc) return rc;
-    caps_bwd_kernel<DOUT, G, true><<<grid, 64 * G, lds, s>>>(*a, cdb, rpc, nbuf);
-  } else {
-    int rc = cy_allow_lds(caps_bwd_kernel<DOUT, G, false>, lds);
-    if (rc) return rc;
-    caps_bwd_kernel<DOUT, G, false><<<grid, 64 * G, lds, s>>>(*a, nullptr, rpc, nbuf);
-  }
-  return 0;
+    kernel<<<grid, 64 * G, lds, s>>>(*a, c, rpc, nbuf);
+    return 0;
+  };
+  const bool saved = cdb != nullptr && a->n_iter - 1 <= CDB_TMAX && G <= 4;    // (six waves share four SIMDs: 256 registers, the variant spills)
+  if (a->n_iter == 3) return saved ? go(caps_bwd_kernel<DOUT, G, true, 3>, cdb) : go(caps_bwd_kernel<DOUT, G, false, 3>, nullptr);
+  return saved ? go(caps_bwd_kernel<DOUT, G, true, 0>, cdb) : go(caps_bwd_kernel<DOUT, G, false, 0>, nullptr);
 }
 
 template <int DOUT>

@@ -180,7 +180,13 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
       // u_hat of the lane's NJ capsules.  The DD4 float4 reads of a capsule's W_ij are inline asm with counted waits,
       // kept PF reads ahead of the FMAs that consume them: left to itself hipcc sinks every ds_read_b128 next to its
       // use and waits lgkmcnt(0) right behind it (an exposed LDS latency per read).
-      constexpr int PF = (DD4 < 5) ? DD4 : 5;
+      // ONE wave per SIMD (WPS = 1): two reads per wait -- a tied wait is an issue slot, and hipcc pads a wait state (s_nop, another slot)
+      // between an asm statement that names a register and the first vector instruction that reads it: per float4 that was 5 slots
+      // for 2 packed FMAs (DarkCapsuleNet3 head, row part of the backward: 5.5 -> 4.9 ms).  Two waves per SIMD fill each other's
+      // slots: there the finer wait is the better one (the same head's forward: 3.6 ms against 3.7 with pairs).
+      constexpr int ST = WPS == 1 ? 2 : 1;
+      constexpr int PF = (DD4 < 4 + ST) ? DD4 : 4 + ST;
+      static_assert(DD4 % 2 == 0 && PF % ST == 0, "the W image is read in pairs of float4");
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
         const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(tb + jk[k] * WS);
@@ -190,23 +196,36 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
 #pragma unroll
         for (int h = 0; h < HP; ++h) uh[k][h] = f32x2{0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < DD4; ++q) {
-          // reads q .. min(q + PF, DD4) - 1 are in flight: wait for all but the younger ones
-          const int younger = (q + PF <= DD4 ? PF : DD4 - q) - 1;
-          f32x4& w = wq[q % PF];
-          switch (younger) {
-            case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w)); break;
-            case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w)); break;
-            case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w)); break;
-            case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w)); break;
-            default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w)); break;
+        for (int q = 0; q < DD4; q += ST) {
+          // reads q .. min(q + PF, DD4) - 1 are in flight: wait for all but those younger than q + ST - 1
+          const int younger = (q + PF <= DD4 ? PF : DD4 - q) - ST;
+          f32x4& w0 = wq[q % PF];
+          f32x4& w1 = wq[(q + ST - 1) % PF];          // (ST = 1: w0 again)
+          if constexpr (ST == 2) {
+            switch (younger) {
+              case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1)); break;
+              case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
+              default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
+            }
+          } else {
+            switch (younger) {
+              case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0)); break;
+              case 3: asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(w0)); break;
+              case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0)); break;
+              case 1: asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(w0)); break;
+              default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0)); break;
+            }
           }
 #pragma unroll
-          for (int e = 0; e < 4; e += 2) {
+          for (int e = 0; e < 4 * ST; e += 2) {
             const int f = 4 * q + e, d = f / DP, h = (f % DP) / 2;          // DP is even: a pair never straddles two rows d
-            uh[k][h] = f32x2{w[e], w[e + 1]} * f32x2{uv[d], uv[d]} + uh[k][h];
+            const f32x4& w = e < 4 ? w0 : w1;
+            uh[k][h] = f32x2{w[e & 3], w[(e & 3) + 1]} * f32x2{uv[d], uv[d]} + uh[k][h];
           }
-          if (q + PF < DD4 && !(DBG & 8)) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w) : "v"(wa), "n"(16 * (q + PF)));
+          if (q + PF < DD4 && !(DBG & 8)) {
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * (q + PF)));
+            if constexpr (ST == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * (q + PF + 1)));
+          }
         }
         if constexpr (!UNI) {
           f32x2 bb = uh[k][0] * V[k][0], dd = f32x2{0.f, 0.f};
