@@ -190,25 +190,45 @@ __device__ __forceinline__ void g4_run(const Wino4WgradArgs& a, float* smem) {
   i32x4g_ xdesc, zdesc, zzdesc, odesc;
   unsigned xsoff = 0, zsoff = 0, xbt = 0;
   bool phantom = false;                         // the cursor stands behind the block's last real chunk
-  auto set_cursor = [&]() {
+  // The chunk offsets RUN (one add per chunk) and the four descriptors are rebuilt only when the image changes: recomputed from (image,
+  // row, column) per chunk they were ~170 scalar instructions -- 64-bit multiplies for every base -- in ONE slot of a stream in which
+  // every instruction of the wave, scalar or not, takes an issue slot.  (No new uniform state: the kernel stands at 100 SGPRs, and
+  // running image pointers pushed it into v_writelane spills.)
+  auto set_desc = [&]() {
     xdesc = g4_desc((const char*)(a.X + (long long)lgb * a.H * a.W * a.Cin) - xshift, phantom ? 0 : ximg_bytes + xshift);
     zdesc = g4_desc(a.dZ + (long long)lgb * a.H * a.W * a.Cout, zimg_bytes);
     if constexpr (BNF) {
       zzdesc = g4_desc(a.Z + (long long)lgb * a.H * a.W * a.Cout, zimg_bytes);
       odesc = g4_desc(a.dZout + (long long)lgb * a.H * a.W * a.Cout, phantom ? 0 : zimg_bytes);
     }
-    xsoff = (unsigned)(((4 * lty) * a.W + 16 * lcx) * a.Cin * 4);
-    zsoff = (unsigned)(((4 * lty) * a.W + 16 * lcx) * a.Cout * 4);
+  };
+  auto set_edges = [&]() {
     xbt = (lty == 0 ? 1u << 28 : 0u) | (lty == a.gh - 1 ? 1u << 29 : 0u) | (lcx == 0 ? 1u << 30 : 0u) | (lcx == a.gw - 1 ? 1u << 31 : 0u);
+  };
+  auto set_row = [&]() {                        // offsets of the first chunk of tile row lty
+    xsoff = (unsigned)((4 * lty) * a.W * a.Cin * 4);
+    zsoff = (unsigned)((4 * lty) * a.W * a.Cout * 4);
+  };
+  auto set_cursor = [&]() {                     // (prologue only)
+    set_desc();
+    set_row();
+    xsoff += (unsigned)(16 * lcx * a.Cin * 4);
+    zsoff += (unsigned)(16 * lcx * a.Cout * 4);
+    set_edges();
   };
   auto advance = [&]() {
     if (lrem <= 0) {
-      if (!phantom) { phantom = true; set_cursor(); }
+      if (!phantom) { phantom = true; set_desc(); }
       return;
     }
     --lrem;
-    if (++lcx == a.gw) { lcx = 0; if (++lty == a.gh) { lty = 0; ++lgb; } }
-    set_cursor();
+    ++lcx; xsoff += (unsigned)(64 * a.Cin); zsoff += (unsigned)(64 * a.Cout);
+    if (lcx == a.gw) {
+      lcx = 0;
+      if (++lty == a.gh) { lty = 0; ++lgb; set_desc(); }
+      set_row();
+    }
+    set_edges();
   };
   // two register sets: at the top of iteration f set f & 1 holds chunk f + 2 and the other set chunk f + 3, both possibly still in
   // flight (a load has two chunks = 2 us to return: with one set -- 1 us -- the S_raw waits were the loop's largest stall)
