@@ -190,7 +190,11 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
   __builtin_amdgcn_s_waitcnt(0x0F70);               // vmcnt(0): first row landed (and the plain W stores are LDS ops)
   __syncthreads();
   const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(Wme + jl * WS);
-  constexpr int PF = (DD4 < 4) ? DD4 : 4;
+  // reads of the W image per tied wait and in flight (routing_rows.hip: a tied wait and the wait state hipcc pads behind it are issue
+  // slots; up to four waves a wave has 512 registers for the deeper ring, the six-wave variants spill as it is)
+  constexpr int ST = G <= 4 ? 4 : 2;
+  constexpr int PF = 2 * ST;
+  static_assert(DD4 % ST == 0 && DD4 >= PF, "the W image is read in groups of ST float4");
 
   // pair h of a Dout-vector in LDS (4-byte aligned: ds_read2_b32); the pad component of an odd Dout reads as 0
   auto ldpair = [&](const float* p, int h) -> f32x2 {
@@ -226,23 +230,24 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 #pragma unroll
       for (int p = 0; p < PF; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[p]) : "v"(wa), "n"(16 * p));
 #pragma unroll
-      for (int q = 0; q < DD4; q += 2) {              // two reads per tied wait (routing_rows.hip: a wait and its s_nop pad are issue slots)
-        const int younger = (q + PF <= DD4 ? PF : DD4 - q) - 2;
-        f32x4& w0 = wq[q % PF];
-        f32x4& w1 = wq[(q + 1) % PF];
-        switch (younger) {
-          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
-          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
+      for (int q = 0; q < DD4; q += ST) {             // ST reads per tied wait
+        const bool more = q + PF <= DD4;              // a whole group is still in flight behind this one
+        if constexpr (ST == 4) {
+          if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]), "+v"(wq[(q + 2) % PF]), "+v"(wq[(q + 3) % PF]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]), "+v"(wq[(q + 2) % PF]), "+v"(wq[(q + 3) % PF]));
+        } else {
+          if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]));
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
+        for (int e = 0; e < 2 * ST; ++e) {
           const int f = 4 * q + 2 * e, d = f / DP, h = (f % DP) / 2;
-          const f32x4& w = e < 2 ? w0 : w1;
+          const f32x4& w = wq[(q + (e >> 1)) % PF];
           uh[h] = f32x2{w[2 * (e & 1)], w[2 * (e & 1) + 1]} * uv[d] + uh[h];
         }
         if (q + PF < DD4) {
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * (q + PF)));
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * (q + PF + 1)));
+#pragma unroll
+          for (int r = 0; r < ST; ++r) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[(q + r) % PF]) : "v"(wa), "n"(16 * (q + PF + r)));
         }
       }
     }
@@ -339,23 +344,27 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
 #pragma unroll
       for (int pq = 0; pq < PF; ++pq) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[pq]) : "v"(wa), "n"(16 * qord(pq)));
 #pragma unroll
-      for (int k = 0; k < DD4; k += 2) {
-        f32x4& w0 = wq[k % PF];
-        f32x4& w1 = wq[(k + 1) % PF];
-        const int younger = (k + PF <= DD4 ? PF : DD4 - k) - 2;    // reads younger than w1
-        switch (younger) {
-          case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
-          default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
+      for (int k = 0; k < DD4; k += ST) {
+        const bool more = k + PF <= DD4;
+        if constexpr (ST == 4) {
+          if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]), "+v"(wq[(k + 2) % PF]), "+v"(wq[(k + 3) % PF]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]), "+v"(wq[(k + 2) % PF]), "+v"(wq[(k + 3) % PF]));
+        } else {
+          if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]));
+          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]));
         }
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const int f0 = 4 * qord(k) + 2 * e, f1 = 4 * qord(k + 1) + 2 * e;
-          acc[f0 / DP] = f32x2{w0[2 * e], w0[2 * e + 1]} * duh[(f0 % DP) / 2] + acc[f0 / DP];
-          acc[f1 / DP] = f32x2{w1[2 * e], w1[2 * e + 1]} * duh[(f1 % DP) / 2] + acc[f1 / DP];
-        }
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int r = 0; r < ST; ++r) {              // (r inner: neighbours feed different accumulators)
+            const int f = 4 * qord(k + r) + 2 * e;
+            const f32x4& w = wq[(k + r) % PF];
+            acc[f / DP] = f32x2{w[2 * e], w[2 * e + 1]} * duh[(f % DP) / 2] + acc[f / DP];
+          }
         if (k + PF < DD4) {
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * qord(k + PF < DD4 ? k + PF : 0)));
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * qord(k + PF + 1 < DD4 ? k + PF + 1 : 0)));
+#pragma unroll
+          for (int r = 0; r < ST; ++r)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[(k + r) % PF]) : "v"(wa), "n"(16 * qord(k + PF + r < DD4 ? k + PF + r : 0)));
         }
       }
 #pragma unroll

@@ -180,13 +180,13 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
       // u_hat of the lane's NJ capsules.  The DD4 float4 reads of a capsule's W_ij are inline asm with counted waits,
       // kept PF reads ahead of the FMAs that consume them: left to itself hipcc sinks every ds_read_b128 next to its
       // use and waits lgkmcnt(0) right behind it (an exposed LDS latency per read).
-      // ONE wave per SIMD (WPS = 1): two reads per wait -- a tied wait is an issue slot, and hipcc pads a wait state (s_nop, another slot)
-      // between an asm statement that names a register and the first vector instruction that reads it: per float4 that was 5 slots
-      // for 2 packed FMAs (DarkCapsuleNet3 head, row part of the backward: 5.5 -> 4.9 ms).  Two waves per SIMD fill each other's
+      // ONE wave per SIMD (WPS = 1): four reads per wait -- a tied wait is an issue slot, and hipcc pads a wait state (s_nop, another slot)
+      // between an asm statement that defines vector registers and the next vector instruction (whatever stands in between): per
+      // float4 that was 5 slots for 2 packed FMAs (DarkCapsuleNet3 head, row part of the backward: 5.5 -> 4.9 ms with pairs).  Two waves per SIMD fill each other's
       // slots: there the finer wait is the better one (the same head's forward: 3.6 ms against 3.7 with pairs).
-      constexpr int ST = WPS == 1 ? 2 : 1;
-      constexpr int PF = (DD4 < 4 + ST) ? DD4 : 4 + ST;
-      static_assert(DD4 % 2 == 0 && PF % ST == 0, "the W image is read in pairs of float4");
+      constexpr int ST = WPS == 1 ? 4 : 1;              // reads per tied wait
+      constexpr int PF = (DD4 < 4 + ST) ? DD4 : 4 + ST; // reads in flight
+      static_assert(DD4 % 4 == 0 && PF % ST == 0, "the W image is read in groups of four float4");
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
         const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(tb + jk[k] * WS);
@@ -200,12 +200,13 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
           // reads q .. min(q + PF, DD4) - 1 are in flight: wait for all but those younger than q + ST - 1
           const int younger = (q + PF <= DD4 ? PF : DD4 - q) - ST;
           f32x4& w0 = wq[q % PF];
-          f32x4& w1 = wq[(q + ST - 1) % PF];          // (ST = 1: w0 again)
-          if constexpr (ST == 2) {
+          if constexpr (ST == 4) {
+            f32x4& w1 = wq[(q + 1) % PF];
+            f32x4& w2 = wq[(q + 2) % PF];
+            f32x4& w3 = wq[(q + 3) % PF];
             switch (younger) {
-              case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1)); break;
-              case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
-              default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
+              case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
+              default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
             }
           } else {
             switch (younger) {
@@ -219,12 +220,13 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
 #pragma unroll
           for (int e = 0; e < 4 * ST; e += 2) {
             const int f = 4 * q + e, d = f / DP, h = (f % DP) / 2;          // DP is even: a pair never straddles two rows d
-            const f32x4& w = e < 4 ? w0 : w1;
+            const f32x4& w = wq[(q + (e >> 2)) % PF];
             uh[k][h] = f32x2{w[e & 3], w[(e & 3) + 1]} * f32x2{uv[d], uv[d]} + uh[k][h];
           }
           if (q + PF < DD4 && !(DBG & 8)) {
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w0) : "v"(wa), "n"(16 * (q + PF)));
-            if constexpr (ST == 2) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(w1) : "v"(wa), "n"(16 * (q + PF + 1)));
+#pragma unroll
+            for (int r = 0; r < ST; ++r)
+              asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[(q + r) % PF]) : "v"(wa), "n"(16 * (q + PF + r < DD4 ? q + PF + r : 0)));
           }
         }
         if constexpr (!UNI) {
