@@ -173,6 +173,106 @@ __global__ __launch_bounds__(256, 1) void conv1_fwd_kernel(Conv1Args a) {
   }
 }
 
+// ---- the activation pass of the bf16 path ("precision": "bf16") on the bf16 matrix cores: K = 27 taps + 5 zeros = two steps of
+// v_mfma_f32_32x32x16_bf16 per channel tile instead of 14 of v_mfma_f32_32x32x2f32 -- 8 MFMAs of 32 cycles per 32-pixel tile against
+// 56 of 64 cycles: the fp32 form is MFMA-bound (1.1 ms at 608 x 608, batch 32, for 3 GB of bf16 output), this one store-bound.
+// Lane (pixel li, k half lh) holds the taps k = 16 s + 8 lh + e, e = 0..7, of step s: image values and weights are rounded to bf16
+// (8 significant bits: the u8 pixels behind the centred image lose nothing but the centring's fraction) and accumulate in fp32; the
+// BatchNorm constants come from the block's fp32 statistics as before.
+typedef __bf16 c1_bf16x8 __attribute__((ext_vector_type(8)));
+template <int NT>
+__global__ __launch_bounds__(256, 1) void conv1_fwd_bf16_kernel(Conv1Args a) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  const int segs = a.Wd / 32;
+  const size_t plane = (size_t)a.H * a.Wd;
+  int toff[16], tky[16], tkx[16];
+  c1_bf16x8 wreg[NT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = 16 * (i >> 3) + 8 * lh + (i & 7);
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, kh = (kk % 9) / 3, kw = kk % 3;
+    tky[i] = k < 27 ? kh - 1 : (1 << 20);   // padding tap: never inside the image -> operand 0
+    tkx[i] = kw - 1;
+    toff[i] = (int)(c * plane) + (kh - 1) * a.Wd + (kw - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[nt][i >> 3][i & 7] = (__bf16)(k < 27 ? a.W[((size_t)(NT * li + nt) * 3 + c) * 9 + kh * 3 + kw] : 0.f);
+  }
+  float bv[NT], asc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    asc[nt] = a.scale[NT * li + nt];
+    bv[nt] = (a.bias != nullptr ? a.bias[NT * li + nt] : 0.f) * asc[nt] + a.shift[NT * li + nt];
+  }
+  auto load_a = [&](long long tile, float (&av)[16]) {
+    const int seg = (int)(tile % segs);
+    const long long row = tile / segs;
+    const int y = (int)(row % a.H), b = (int)(row / a.H);
+    const int x = seg * 32 + li;
+    const float* px = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + x;
+    const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;    // uniform
+    if (inner) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) av[i] = (i < 8 || lh == 0 || (i & 7) < 3) ? px[toff[i]] : 0.f;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = (unsigned)(y + tky[i]) < (unsigned)a.H && (unsigned)(x + tkx[i]) < (unsigned)a.Wd;
+        const float v = px[ok ? toff[i] : 0];
+        av[i] = ok ? v : 0.f;
+      }
+    }
+  };
+  float acur[16], anext[16];
+  long long tile = gw;
+  if (tile < a.ntiles) load_a(tile, acur);
+  for (; tile < a.ntiles; tile += nw) {
+    const long long tn = tile + nw;
+    if (tn < a.ntiles) load_a(tn, anext);   // one tile of latency cover
+    c1_bf16x8 a8[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a8[i >> 3][i & 7] = (__bf16)acur[i];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s], wreg[nt][s], acc[nt], 0, 0, 0);
+    // epilogue: as conv1_fwd_kernel<NT, true, true, true> (a lane owns NT consecutive channels of each of its 16 pixels)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = (r & 3) + 8 * (r >> 2) + 4 * lh;
+      unsigned short h[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float y = __builtin_fmaf(acc[nt][r], asc[nt], bv[nt]);
+        const float ys = y * a.slope;
+        float v;
+        asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(y), "v"(ys));
+        const __bf16 b = (__bf16)v;
+        h[nt] = *(const unsigned short*)&b;
+      }
+      unsigned short* yb = (unsigned short*)a.Y + (size_t)tile * 32 * a.Cout + NT * li + (size_t)p * a.Cout;
+      if constexpr (NT == 4) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        CY_C1_ST((u32x2_t{(unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16)}), (u32x2_t*)yb);
+      } else if constexpr (NT == 2) {
+        *(unsigned*)yb = (unsigned)h[0] | ((unsigned)h[1] << 16);
+      } else {
+        yb[0] = h[0];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acur[i] = anext[i];
+  }
+}
+
 // ---- weight gradient of the same layer: dW[co][c][kh][kw] = sum over pixels of dZ[pixel][co] * x[c][y + kh - 1][x + kw - 1].
 // The pixels are the MFMA k dimension: D[co (32 NT rows)][tap (27 of 32 columns)] += A[co][pixel] B[pixel][tap] with
 // A = dZ (lane = channel, k half = pixel parity: 128 contiguous bytes per pixel) and B = the image patch (lane = tap:
@@ -450,6 +550,180 @@ __global__ __launch_bounds__(256, 1) void conv1_bn_bwd_kernel(Conv1BnArgs a) {
   }
 }
 
+// ---- PASS 2 of the bf16 path on the bf16 matrix cores (cy_conv1_bn_bwd_onepass_bf16): the recomputation of z is the forward's own
+// two v_mfma_f32_32x32x16_bf16 steps (conv1_fwd_bf16_kernel: the same operands in the same order, so the mask lrelu'(y) is the one
+// the stored activation was formed with), and the weight gradient of d takes the pixels as its k dimension in the order that needs no
+// data movement at all: step s of channel tile nt multiplies the lane's OWN accumulator rows r = 8 s .. 8 s + 7 (pixels p(r, lh),
+// its 8 k values) with the patch values of the same pixels that the lane of tap li has fetched (bw[8 s .. 8 s + 7], as in the fp32
+// kernel).  16 bf16 MFMAs of 32 cycles per 32-pixel tile against 120 fp32 MFMAs of 64 (2.37 ms at 608 x 608, batch 32: the launch
+// was bound by them); what is left is the read of dA (3 GB) and ~500 vector instructions per tile.
+// (PASS as in conv1_bn_bwd_kernel: 0 the sums, 1 the weight gradient of dz, 2 the one-pass form)
+template <int NT, int PASS>
+__global__ __launch_bounds__(256, 1) void conv1_bn_bwd_bf16mm_kernel(Conv1BnArgs a) {
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  const int segs = a.Wd / 32;
+  const size_t plane = (size_t)a.H * a.Wd;
+  // forward operand geometry (conv1_fwd_bf16_kernel): lane = pixel li, taps k = 16 s + 8 lh + e
+  int toff[16], tky[16], tkx[16];
+  c1_bf16x8 wreg[NT][2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int k = 16 * (i >> 3) + 8 * lh + (i & 7);
+    const int kk = k < 27 ? k : 0;
+    const int c = kk / 9, kh = (kk % 9) / 3, kw = kk % 3;
+    tky[i] = k < 27 ? kh - 1 : (1 << 20);
+    tkx[i] = kw - 1;
+    toff[i] = (int)(c * plane) + (kh - 1) * a.Wd + (kw - 1);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+      wreg[nt][i >> 3][i & 7] = (__bf16)(k < 27 ? a.W[((size_t)(NT * li + nt) * 3 + c) * 9 + kh * 3 + kw] : 0.f);
+  }
+  // weight-gradient operand geometry (conv1_wgrad_kernel): lane = tap li, k value (s, e) = pixel p(8 s + e, lh)
+  const int kt = li < 27 ? li : 0;
+  const int wc = kt / 9, wkh = (kt % 9) / 3, wkw = kt % 3;
+  const int woff = (int)(wc * plane) + (wkh - 1) * a.Wd + (wkw - 1) + 4 * lh;    // + (r & 3) + 8 (r >> 2)
+  float bv[NT], sc[NT], sh[NT], is[NT], nm[NT], m1[NT], m2[NT], b1[NT], b2[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = NT * li + nt;
+    bv[nt] = a.bias != nullptr ? a.bias[c] : 0.f;
+    sc[nt] = a.scale[c]; sh[nt] = a.shift[c];
+    sh[nt] = __builtin_fmaf(bv[nt], sc[nt], sh[nt]);          // y = acc * scale + (bias * scale + shift)
+    is[nt] = PASS < 2 ? a.invstd[c] : 0.f;                    // xhat = acc * invstd + (bias - mean) * invstd
+    nm[nt] = PASS < 2 ? (bv[nt] - a.mean[c]) * is[nt] : 0.f;
+    m1[nt] = PASS == 1 ? (float)(a.red_in[2 * c] * a.inv_count) : 0.f;
+    m2[nt] = PASS == 1 ? (float)(a.red_in[2 * c + 1] * a.inv_count) : 0.f;
+    b1[nt] = 0.f; b2[nt] = 0.f;
+  }
+  auto load_img = [&](long long tile, float (&av)[16], float (&bw)[16]) {
+    const int seg = (int)(tile % segs);
+    const long long row = tile / segs;
+    const int y = (int)(row % a.H), b = (int)(row / a.H);
+    const float* p0 = a.X + (size_t)b * 3 * plane + (size_t)y * a.Wd + seg * 32;
+    const float* px = p0 + li;
+    const bool inner = y >= 1 && y + 1 < a.H && seg >= 1 && seg + 1 < segs;    // uniform
+    if (inner) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) av[i] = (i < 8 || lh == 0 || (i & 7) < 3) ? px[toff[i]] : 0.f;
+      if (PASS >= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bw[r] = p0[woff + (r & 3) + 8 * (r >> 2)];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bool ok = (unsigned)(y + tky[i]) < (unsigned)a.H && (unsigned)(seg * 32 + li + tkx[i]) < (unsigned)a.Wd;
+        const float v = px[ok ? toff[i] : 0];
+        av[i] = ok ? v : 0.f;
+      }
+      if (PASS >= 1) {
+        const bool rowok = (unsigned)(y + wkh - 1) < (unsigned)a.H;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int pcol = (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const bool ok = rowok && (unsigned)(seg * 32 + pcol + wkw - 1) < (unsigned)a.Wd;
+          const float v = p0[ok ? woff + (r & 3) + 8 * (r >> 2) : 0];
+          bw[r] = ok ? v : 0.f;
+        }
+      }
+    }
+  };
+  f32x16 accw[NT];                          // PASS >= 1: dW of dz (1) / of d (2): [channel NT row + nt][tap]
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accw[nt][r] = 0.f;
+  float acur[16], anext[16], bwcur[16], bwnext[16];
+  long long tile = gw;
+  if (tile < a.ntiles) load_img(tile, acur, bwcur);
+  for (; tile < a.ntiles; tile += nw) {
+    // dA (bf16) of this tile in the accumulator layout: requested first, used after the recompute MFMAs
+    float g[16][NT];
+    {
+      const unsigned short* pg = (const unsigned short*)a.dA + (size_t)tile * 32 * a.Cout + NT * li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned short* q = pg + (size_t)((r & 3) + 8 * (r >> 2) + 4 * lh) * a.Cout;
+        if constexpr (NT == 4) {
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          const u32x2_t w = CY_C1_LD((const u32x2_t*)q);
+          g[r][0] = __uint_as_float(w[0] << 16); g[r][1] = __uint_as_float(w[0] & 0xffff0000u);
+          g[r][2] = __uint_as_float(w[1] << 16); g[r][3] = __uint_as_float(w[1] & 0xffff0000u);
+        } else if constexpr (NT == 2) {
+          const unsigned w = *(const unsigned*)q;
+          g[r][0] = __uint_as_float(w << 16); g[r][1] = __uint_as_float(w & 0xffff0000u);
+        } else {
+          g[r][0] = __uint_as_float((unsigned)q[0] << 16);
+        }
+      }
+    }
+    const long long tn = tile + nw;
+    if (tn < a.ntiles) load_img(tn, anext, bwnext);
+    c1_bf16x8 a8[2], b8[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { a8[i >> 3][i & 7] = (__bf16)acur[i]; if (PASS >= 1) b8[i >> 3][i & 7] = (__bf16)bwcur[i]; }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a8[s], wreg[nt][s], acc[nt], 0, 0, 0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      c1_bf16x8 d8[2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float y = __builtin_fmaf(acc[nt][r], sc[nt], sh[nt]);
+        const float gv = g[r][nt];
+        const float d = y > 0.f ? gv : gv * a.slope;
+        if (PASS == 0) {
+          const float xh = __builtin_fmaf(acc[nt][r], is[nt], nm[nt]);
+          b1[nt] += d;
+          b2[nt] = __builtin_fmaf(d, xh, b2[nt]);
+        } else if (PASS == 1) {
+          const float xh = __builtin_fmaf(acc[nt][r], is[nt], nm[nt]);
+          d8[r >> 3][r & 7] = (__bf16)(sc[nt] * (d - m1[nt] - xh * m2[nt]));
+        } else {
+          b1[nt] += d;
+          d8[r >> 3][r & 7] = (__bf16)d;
+        }
+      }
+      if (PASS >= 1) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) accw[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d8[s], b8[s], accw[nt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acur[i] = anext[i]; if (PASS >= 1) bwcur[i] = bwnext[i]; }
+  }
+  if (PASS == 0 || PASS == 2) {
+    double* rd = a.red_out + (size_t)((blockIdx.x * 4 + wave) % CY_STATS_COPIES) * a.Cout * 2;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float s1 = b1[nt] + __shfl_xor(b1[nt], 32, 64), s2 = b2[nt] + __shfl_xor(b2[nt], 32, 64);
+      if (lh == 0) {
+        atomicAdd(rd + 2 * (NT * li + nt), (double)s1);
+        if (PASS == 0) atomicAdd(rd + 2 * (NT * li + nt) + 1, (double)s2);
+      }
+    }
+  }
+  if (PASS >= 1) {
+    float* out = a.slabs + (size_t)gw * a.Cout * 32;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = NT * ((r & 3) + 8 * (r >> 2) + 4 * lh) + nt;
+        out[(size_t)co * 32 + li] = accw[nt][r];
+      }
+  }
+}
+
 // dW[co][c][kh][kw] (= [co][27]) = sum over the waves' slabs in a fixed order: one block per channel, thread = (tap,
 // slab group): 128 contiguous bytes per slab row, 8 partial sums per tap combined through LDS
 __global__ __launch_bounds__(256) void conv1_wgrad_finish_kernel(const float* __restrict__ slabs, float* __restrict__ dW,
@@ -590,9 +864,15 @@ static int conv1_bn_bwd_reduce_impl(const char* who, const float* X, const float
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (da_bf16) {
+#ifdef CY_C1_F32MM
     if (Cout == 128) conv1_bn_bwd_kernel<4, 0, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 0, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else conv1_bn_bwd_kernel<1, 0, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+#else
+    if (Cout == 128) conv1_bn_bwd_bf16mm_kernel<4, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else if (Cout == 64) conv1_bn_bwd_bf16mm_kernel<2, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else conv1_bn_bwd_bf16mm_kernel<1, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
+#endif
   } else {
     if (Cout == 128) conv1_bn_bwd_kernel<4, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 0><<<(unsigned)blocks, 256, 0, s>>>(a);
@@ -631,9 +911,15 @@ static int conv1_bn_bwd_onepass_impl(const char* who, const float* X, const floa
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (da_bf16) {
+#ifdef CY_C1_F32MM
     if (Cout == 128) conv1_bn_bwd_kernel<4, 2, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 2, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else conv1_bn_bwd_kernel<1, 2, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+#else
+    if (Cout == 128) conv1_bn_bwd_bf16mm_kernel<4, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else if (Cout == 64) conv1_bn_bwd_bf16mm_kernel<2, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else conv1_bn_bwd_bf16mm_kernel<1, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
+#endif
   } else {
     if (Cout == 128) conv1_bn_bwd_kernel<4, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 2><<<(unsigned)blocks, 256, 0, s>>>(a);
@@ -680,9 +966,15 @@ static int conv1_bn_bwd_wgrad_impl(const char* who, bool da_bf16, const float* X
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   if (da_bf16) {
+#ifdef CY_C1_F32MM
     if (Cout == 128) conv1_bn_bwd_kernel<4, 1, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 1, true><<<(unsigned)blocks, 256, 0, s>>>(a);
     else conv1_bn_bwd_kernel<1, 1, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+#else
+    if (Cout == 128) conv1_bn_bwd_bf16mm_kernel<4, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else if (Cout == 64) conv1_bn_bwd_bf16mm_kernel<2, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+    else conv1_bn_bwd_bf16mm_kernel<1, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
+#endif
   } else {
     if (Cout == 128) conv1_bn_bwd_kernel<4, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
     else if (Cout == 64) conv1_bn_bwd_kernel<2, 1><<<(unsigned)blocks, 256, 0, s>>>(a);
@@ -759,9 +1051,16 @@ extern "C" int cy_conv1_3x3_fwd_act_bf16(const float* X, const float* W, const f
   int rc = conv1_blocks(a.ntiles, &blocks, "cy_conv1_3x3_fwd_act_bf16");
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  // (-DCY_C1_F32MM: the fp32 matrix cores with a bf16 store, the round-2 form -- a developer switch for A/B timing)
+#ifdef CY_C1_F32MM
   if (Cout == 128) conv1_fwd_kernel<4, true, true, true><<<(unsigned)blocks, 256, 0, s>>>(a);
   else if (Cout == 64) conv1_fwd_kernel<2, true, true, true><<<(unsigned)blocks, 256, 0, s>>>(a);
   else conv1_fwd_kernel<1, true, true, true><<<(unsigned)blocks, 256, 0, s>>>(a);
+#else
+  if (Cout == 128) conv1_fwd_bf16_kernel<4><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else if (Cout == 64) conv1_fwd_bf16_kernel<2><<<(unsigned)blocks, 256, 0, s>>>(a);
+  else conv1_fwd_bf16_kernel<1><<<(unsigned)blocks, 256, 0, s>>>(a);
+#endif
   CY_LAUNCH_CHECK("cy_conv1_3x3_fwd_act_bf16");
   return 0;
 }

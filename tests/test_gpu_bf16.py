@@ -40,6 +40,72 @@ BF16_CASES = [
 ]
 
 
+@pytest.mark.parametrize('cout,B,H,W', [(128, 2, 12, 64), (64, 1, 37, 96), (32, 3, 5, 32)])
+def test_first_block_activation_on_the_bf16_matrix_cores(cout, B, H, W):
+    """cy_conv1_3x3_fwd_act_bf16 (first block of the bf16 path: lrelu((conv(x) + b) * scale + shift) -> bf16) multiplies on
+    v_mfma_f32_32x32x16_bf16: with image and weights exactly representable in bf16 the only roundings are the fp32 accumulation and
+    the ONE rounding of the result (half an ulp of bf16 = 2^-9 of the value, at most 2^-8 = 3.9e-3 of the maximum); with arbitrary fp32 inputs the
+    operands' rounding to bf16 adds its 2^-9 per term (1e-2).  Border tiles (rows 0 / H-1, first / last 32-pixel segment) included."""
+    from capsyolo_amd import ops
+    for exact in (True, False):
+        g = torch.Generator().manual_seed(11 + cout)
+        x = torch.randn(B, 3, H, W, generator=g) * 60.0
+        w = torch.randn(cout, 3, 3, 3, generator=g) * 0.2
+        if exact:
+            x, w = x.to(BF).float(), w.to(BF).float()
+        b = torch.randn(cout, generator=g) * 0.1
+        sc = torch.rand(cout, generator=g) * 0.05 + 0.01
+        sh = torch.randn(cout, generator=g) * 0.3
+        ref = F.leaky_relu((F.conv2d(x.double(), w.double(), b.double(), padding=1) * sc.double().view(1, -1, 1, 1)
+                            + sh.double().view(1, -1, 1, 1)), 0.1).permute(0, 2, 3, 1)
+        out = ops.conv1_affine_act(x.to(dev()), w.to(dev()), b.to(dev()), sc.to(dev()), sh.to(dev()), 0.1, out_bf16=True)
+        assert out.dtype == BF and tuple(out.shape) == (B, H, W, cout)
+        err = float((out.double().cpu() - ref).abs().max() / ref.abs().max())
+        assert err < (4e-3 if exact else 1e-2), (exact, err)
+
+
+@pytest.mark.parametrize('B,H,W,cout', [(4, 32, 64, 128), (2, 48, 96, 64), (4, 256, 256, 128)])
+def test_first_block_of_the_bf16_path(B, H, W, cout):
+    """The first conv -> BatchNorm -> LeakyReLU block of the bf16 path (Cin = 3: csrc/conv1.hip on v_mfma_f32_32x32x16_bf16, bf16
+    activation out, bf16 gradient in) against torch fp64 modules on a bf16-representable image and weights: activation, running
+    statistics and every gradient, through the two-pass backward (small inputs) and the one-pass backward on the patch moments
+    (from 2^18 pixels on).  What differs from fp64: the rounding of the activation and of d = dA * lrelu' to bf16."""
+    from capsyolo_amd import models, ops
+    x = rnd_bf((B, 3, H, W), 31, 40.0)
+    conv = torch.nn.Conv2d(3, cout, 3, 1, padding=1).double()
+    bn = torch.nn.BatchNorm2d(cout).double()
+    with torch.no_grad():
+        conv.weight.copy_(rnd_bf(tuple(conv.weight.shape), 32, 0.2).double())
+        conv.bias.copy_(rnd_bf((cout,), 33, 0.1).double())
+        bn.weight.copy_((rnd_bf((cout,), 34, 0.2) + 1.0).double())
+        bn.bias.copy_(rnd_bf((cout,), 35, 0.2).double())
+    a = F.leaky_relu(bn(conv(x.double())), 0.1)
+    ga = rnd_bf(tuple(a.shape), 36)
+    a.backward(ga.double())
+    hc = models.HipConv2d(3, cout, 3, 1, 1)
+    hb = models.HipBatchNorm2d(cout)
+    with torch.no_grad():
+        hc.weight.copy_(conv.weight.float()); hc.bias.copy_(conv.bias.float())
+        hb.weight.copy_(bn.weight.float()); hb.bias.copy_(bn.bias.float())
+    hc.cuda(); hb.cuda().train()
+    cfg = ops.ConvBlockCfg(3, 1, 1, True, hb, 0.1, 'first')
+    cfg.out_bf16 = True
+    ops.timer.reset(); ops.timer.enabled = True
+    try:
+        out = ops.conv_block(x.cuda(), hc.weight, hc.bias, hb.weight, hb.bias, cfg)
+        assert out.dtype == BF and tuple(out.shape) == (B, H, W, cout)
+        out.backward(ga.permute(0, 2, 3, 1).contiguous().cuda().to(BF))
+        keys = set(k.split('/')[0] for k in ops.timer.events)
+    finally:
+        ops.timer.enabled = False
+    onepass = B * H * W >= ops.CONV1_MOMENTS_MIN_PIXELS
+    assert ('conv1_bn_bwd_onepass' in keys) == onepass and ('conv1_bn_bwd_wgrad' in keys) == (not onepass), keys
+    assert rel_l2(out.float().permute(0, 3, 1, 2), a) < 1e-2
+    assert rel_l2(hc.weight.grad, conv.weight.grad) < 2e-2
+    assert rel_l2(hb.weight.grad, bn.weight.grad) < 2e-2 and rel_l2(hb.bias.grad, bn.bias.grad) < 2e-2
+    assert rel_l2(hb.running_mean, bn.running_mean) < 1e-3 and rel_l2(hb.running_var, bn.running_var) < 1e-3
+
+
 @pytest.mark.parametrize('case', BF16_CASES)
 def test_conv_bf16_fwd_dgrad_wgrad(case):
     from capsyolo_amd import ops
@@ -186,8 +252,8 @@ def test_conv_bn_lrelu_block_bf16(case):
 
 
 def _oracle_bf16_forward(net, x, g):
-    """The oracle's DarkCapsuleNet forward with the bf16 path's roundings restated on the CPU: block 1 in fp32 and its
-    activation rounded to bf16; blocks 2..5 with bf16 weights, fp32 accumulation, BatchNorm statistics from the fp32
+    """The oracle's DarkCapsuleNet forward with the bf16 path's roundings restated on the CPU: block 1 with bf16 operands of its
+    convolution, fp32 statistics and its activation rounded to bf16; blocks 2..5 with bf16 weights, fp32 accumulation, BatchNorm statistics from the fp32
     conv output, normalisation applied to the bf16-rounded conv output, activations rounded to bf16 (the last one
     stays fp32: the routing head is an fp32 kernel).  torch's cast is differentiable (identity), so autograd gives the
     matching gradients up to the roundings of the backward tensors."""
@@ -198,7 +264,14 @@ def _oracle_bf16_forward(net, x, g):
     for i in range(1, 6):
         conv, bn, act = mods['conv_%d' % i], mods['bn_%d' % i], mods['relu_%d' % i]
         if i == 1:
-            h = rb(act(bn(conv(h))))
+            # the first block multiplies on the bf16 matrix cores (image and weights rounded to bf16, fp32 accumulation) and normalises
+            # with the statistics of the EXACT fp32 convolution (they come from the patch moments / the fp32 statistics pass)
+            ze = conv(h)
+            mean, var = ze.mean(dim=(0, 2, 3)), ze.var(dim=(0, 2, 3), unbiased=False)
+            zb = F.conv2d(rb(h), rb(conv.weight), conv.bias, stride=conv.stride, padding=conv.padding)
+            yv = (zb - mean[None, :, None, None]) / torch.sqrt(var[None, :, None, None] + bn.eps) * bn.weight[None, :, None, None] \
+                + bn.bias[None, :, None, None]
+            h = rb(act(yv))
             continue
         z = F.conv2d(h, rb(conv.weight), conv.bias, stride=conv.stride, padding=conv.padding)
         mean, var = z.mean(dim=(0, 2, 3)), z.var(dim=(0, 2, 3), unbiased=False)
