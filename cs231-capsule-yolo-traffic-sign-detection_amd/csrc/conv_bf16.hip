@@ -866,6 +866,20 @@ struct WgArgs {
   long long nchunk;
 };
 
+// developer knob for timing experiments (results are wrong when set): 1 one MFMA per chunk, 2 every load out of range (no memory traffic)
+#ifndef CY_WG_DBG
+#define CY_WG_DBG 0
+#endif
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ wg_i32x4 wg_desc(const void* p, unsigned bytes) {
+  const unsigned long long b = (unsigned long long)(uintptr_t)p;
+  return wg_i32x4{(int)(unsigned)b, (int)(unsigned)((b >> 32) & 0xffffu), (int)bytes, 0x00020000};
+}
+// loads hipcc does not count (see wgrad_bf16_kernel); waited for by hand
+__device__ __forceinline__ void wg_load(u32x4_t& dst, wg_i32x4 desc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff));
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const u16* p0, const u16* p1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
@@ -885,11 +899,13 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   constexpr int WCI = NW / (WCO * TG), CO_T = 32 * WCO, CI_T = (KH == 3) ? 64 : 32 * (4 / WCO), CI_W = CI_T / WCI, NT = CI_W / 32;
   constexpr int KHG = KH / TG;                      // kernel rows per tap group
   static_assert(CI_W % 32 == 0 && NT >= 1 && KH % TG == 0 && WCI >= 1, "wave tile");
-  constexpr int PW = 32, PXW = (PW - 1) * STRIDE + KH, TAPS = KH * KH;
+  // work unit: PR = 2 output rows x PW = 32 pixels (64 pixels = four 16-pixel k slices per barrier; the XR = KH + STRIDE input rows they
+  // touch are staged once: a third fewer input bytes than two one-row units, and half the barriers per MFMA)
+  constexpr int PW = 32, PR = 2, PIX = PW * PR, PXW = (PW - 1) * STRIDE + KH, XR = (PR - 1) * STRIDE + KH, TAPS = KH * KH;
   constexpr int DZB = CO_T * 2 + 64;                                         // bytes per dZ pixel row in LDS
   constexpr int XB = (STRIDE == 1) ? CI_T * 2 + 64 : (CI_T == 32 ? 96 : 160); // bytes per X pixel in LDS
-  constexpr int DZ_IMG = PW * DZB, X_IMG = KH * PXW * XB;
-  constexpr int DZ_CH = PW * (CO_T / 8), X_CH = KH * PXW * (CI_T / 8);        // 16-byte pieces per chunk
+  constexpr int DZ_IMG = PIX * DZB, X_IMG = XR * PXW * XB;
+  constexpr int DZ_CH = PIX * (CO_T / 8), X_CH = XR * PXW * (CI_T / 8);       // 16-byte pieces per chunk
   constexpr int NDZ = (DZ_CH + NTHR - 1) / NTHR, NX = (X_CH + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* dzimg = smem_raw;                  // [2][DZ_IMG]
@@ -914,44 +930,92 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[k][nt][r] = 0.f;
 
-  u32x4_t rdz[NDZ], rx[NX];
-  auto load_chunk = [&](long long cid) {
-    const int cw = (int)(cid % CW);
-    const long long rr = cid / CW;
-    const int oy = (int)(rr % a.Ho), b = (int)(rr / a.Ho);
+  // TWO register sets for the staged chunk: the loads of chunk c + 2 are issued while chunk c is multiplied and chunk c + 1 waits in the
+  // other set.  The loads are inline asm through buffer descriptors of the image, waited for by hand: tracked by hipcc, the exec-masked
+  // loads drew `s_waitcnt vmcnt(0)` in front of every LDS store and `__syncthreads()` drains the vector-memory queue as well, so a
+  // chunk's 24 KB per CU were requested and awaited inside the same chunk: 24 KB in flight against ~2 us of loaded HBM latency is the
+  // 1.3 us per chunk the launch took whatever else the loop did (conv_2 at 608 x 608: 36 GB through L2 in 7.5 ms).
+  //  * padding and items that do not exist get the offset 2^31, beyond every descriptor's num_records: zeros, no access, no exec mask
+  //    (the range check sees the vector offset only, so top / bottom rows are flagged like left / right columns);
+  //  * a block whose chunk range has ended keeps loading PHANTOM chunks (num_records = 0): the loop issues the same NL loads in every
+  //    iteration, and the wait in front of the LDS stores is the constant vmcnt(NL).
+  constexpr int NL = NDZ + NX;
+  constexpr int NSET = NL <= 5 ? 2 : 1;            // (conv_3's 64 x 64-channel tile stages 8 pieces per thread: two sets spill)
+  u32x4_t rdz[NSET][NDZ], rx[NSET][NX];
+  unsigned dzv[NDZ], xv[NX], xfl[NX];
+  int dzpx[NDZ], xjj[NX];                           // (packed: the column in bits 0..7, the row above)
+#pragma unroll
+  for (int i = 0; i < NDZ; ++i) {
+    const int c = t + NTHR * i;
+    const int px = c / (CO_T / 8), q = c % (CO_T / 8);
+    dzv[i] = c < DZ_CH ? (unsigned)((((px / PW) * a.Wo + (px % PW)) * a.Cout + co0 + q * 8) * 2) : 0x80000000u;
+    dzpx[i] = (px % PW) | ((px / PW) << 8);          // column, and bit 8: the chunk's second output row
+  }
+#pragma unroll
+  for (int i = 0; i < NX; ++i) {
+    const int c = t + NTHR * i;
+    const int q = c % (CI_T / 8), pj = c / (CI_T / 8), j = pj % PXW, r = pj / PXW;
+    xv[i] = c < X_CH ? (unsigned)(((r * a.Wi + j) * a.Cin + ci0 + q * 8) * 2) : 0x80000000u;
+    xjj[i] = j | (r << 8);                            // patch column, and from bit 8 on: patch row
+    xfl[i] = (r == 0 ? 1u : 0u) | (j == 0 ? 2u : 0u);
+  }
+  const unsigned xshift = (unsigned)((a.Wi + 1) * a.Cin * 2);      // the X descriptor's base stands one row and one pixel in front of the image
+  const unsigned ximg_b = (unsigned)(a.Hi * a.Wi * a.Cin * 2), zimg_b = (unsigned)(a.Ho * a.Wo * a.Cout * 2);
+  // chunk cursor (segment of 32 pixels, output row, image) of the NEXT chunk to load: it RUNS -- derived from the chunk index per
+  // chunk, the two 64-bit division pairs were ~240 of the ~290 scalar instructions a wave issued per chunk next to its 18 MFMAs
+  const int RH = (a.Ho + PR - 1) / PR;             // row pairs per image
+  int ccw = (int)(c_lo % CW), coy, cb_;
+  {
+    const long long rr = c_lo / CW;
+    coy = (int)(rr % RH) * PR; cb_ = (int)(rr / RH);
+  }
+  long long left = c_hi - c_lo;                     // real chunks not yet requested
+  auto load_chunk = [&](auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+    const int cw = ccw, oy = coy, b = cb_;
+    if (++ccw == CW) { ccw = 0; coy += PR; if (coy >= a.Ho) { coy = 0; ++cb_; } }
+    const bool real = left > 0;
+    --left;
     const int ox0 = cw * PW;
+    const wg_i32x4 dzd = wg_desc(a.dZ + (long long)b * a.Ho * a.Wo * a.Cout, real ? zimg_b : 0u);
+    const wg_i32x4 xd = wg_desc((const char*)(a.X + (long long)b * a.Hi * a.Wi * a.Cin) - xshift, real ? ximg_b + xshift : 0u);
+    const unsigned zso = (unsigned)__builtin_amdgcn_readfirstlane(((oy * a.Wo + ox0) * a.Cout) * 2);
+    const unsigned xso = (unsigned)__builtin_amdgcn_readfirstlane(((oy * STRIDE * a.Wi + ox0 * STRIDE) * a.Cin) * 2);
+    // first pixel / output row / patch column / patch row beyond the image (row limits from bit 8 on, as in dzpx / xjj: one compare
+    // of the packed (row, column) against (row limit, 255) and one of the column)
+    const int zlim = a.Wo - ox0, zrlim = a.Ho - oy, xlim = a.Wi - (ox0 * STRIDE - 1), xrlim = a.Hi - (oy * STRIDE - 1);
+    const unsigned bt = (oy == 0 ? 1u : 0u) | (cw == 0 ? 2u : 0u);
 #pragma unroll
     for (int i = 0; i < NDZ; ++i) {
-      const int c = t + NTHR * i;
-      const int px = c / (CO_T / 8), q = c % (CO_T / 8);
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (c < DZ_CH && ox0 + px < a.Wo)
-        v = *(const u32x4_t*)(a.dZ + (((long long)b * a.Ho + oy) * a.Wo + ox0 + px) * a.Cout + co0 + q * 8);
-      rdz[i] = v;
+      const bool bad = (CY_WG_DBG & 2) || (dzpx[i] & 255) >= zlim || (dzpx[i] >> 8) >= zrlim;
+      wg_load(rdz[S][i], dzd, bad ? 0x80000000u : dzv[i], zso);
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const int c = t + NTHR * i;
-      const int q = c % (CI_T / 8), pj = c / (CI_T / 8), j = pj % PXW, r = pj / PXW;
-      const int iy = oy * STRIDE - 1 + r, ix = ox0 * STRIDE - 1 + j;
-      u32x4_t v = {0u, 0u, 0u, 0u};
-      if (c < X_CH && (unsigned)iy < (unsigned)a.Hi && (unsigned)ix < (unsigned)a.Wi)
-        v = *(const u32x4_t*)(a.X + (((long long)b * a.Hi + iy) * a.Wi + ix) * a.Cin + ci0 + q * 8);
-      rx[i] = v;
+      const bool bad = (CY_WG_DBG & 2) || (xfl[i] & bt) != 0u || (xjj[i] & 255) >= xlim || (xjj[i] >> 8) >= xrlim;
+      wg_load(rx[S][i], xd, bad ? 0x80000000u : xv[i], xso);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto wait_set = [&](auto set_c, auto n_c) {       // all but the n youngest vector-memory operations have landed; ties the set's registers
+    constexpr int S = decltype(set_c)::value, N = decltype(n_c)::value;
+#pragma unroll
+    for (int i = 0; i < NDZ; ++i) { u32x4_t& r = rdz[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
+#pragma unroll
+    for (int i = 0; i < NX; ++i) { u32x4_t& r = rx[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
+  };
+  auto store_chunk = [&](auto set_c, int buf) {
+    constexpr int S = decltype(set_c)::value;
 #pragma unroll
     for (int i = 0; i < NDZ; ++i) {
       const int c = t + NTHR * i;
       const int px = c / (CO_T / 8), q = c % (CO_T / 8);
-      if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = rdz[i];
+      if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = rdz[S][i];
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       const int c = t + NTHR * i;
       const int q = c % (CI_T / 8), pj = c / (CI_T / 8);
-      if (c < X_CH) *(u32x4_t*)(ximg + buf * X_IMG + pj * XB + q * 16) = rx[i];
+      if (c < X_CH) *(u32x4_t*)(ximg + buf * X_IMG + pj * XB + q * 16) = rx[S][i];
     }
   };
 
@@ -962,34 +1026,86 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   const int a_off = (kh8 + q4) * DZB + (wco * 32 + cb * 16 + 4 * p4) * 2;                 // + ks * 16 * DZB (+ 4 * DZB)
   const int b_off = ((kh8 + q4) * STRIDE) * XB + (wci * CI_W + cb * 16 + 4 * p4) * 2;     // + tap / tile / ks terms
 
-  if (c_lo < c_hi) {
-    load_chunk(c_lo);
-    store_chunk(0);
-  }
-  __syncthreads();
-  for (long long cid = c_lo; cid < c_hi; ++cid) {
-    const int cur = (int)((cid - c_lo) & 1);
-    const bool more = cid + 1 < c_hi;
-    if (more) load_chunk(cid + 1);
-    const unsigned char* dzb = dzimg + cur * DZ_IMG + a_off;
-    const unsigned char* xb = ximg + cur * X_IMG + b_off;
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using N0 = std::integral_constant<int, 0>;
+  load_chunk(S0{});
+  wait_set(S0{}, N0{});
+  store_chunk(S0{}, 0);
+  if constexpr (NSET == 2) load_chunk(S0{});        // chunk c_lo + 1 (or a phantom) waits in set 0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (not __syncthreads(): its fence would wait for the loads in flight)
+  // chunk cid lies in LDS buffer P = (cid - c_lo) & 1; set P holds chunk cid + 1, set 1 - P receives chunk cid + 2
+  auto body = [&](auto par_c, long long cid) {
+    constexpr int P = decltype(par_c)::value;
+    load_chunk(std::integral_constant<int, NSET == 2 ? 1 - P : 0>{});
+    // Fragment reads as inline asm, the B fragments through a ring of three kept AHEAD of their MFMAs with counted waits: every MFMA needs
+    // a fresh transposed B fragment, and left to hipcc each read stood right in front of its MFMA with its own wait (15 waits for 18
+    // MFMAs; the ring holds three): an LDS round trip per MFMA and wave, which two waves per SIMD only half cover (mfma_busy 0.39).
+    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = 3;     // (2 NKS + 2 RING <= 15: lgkmcnt is a 4-bit counter)
+    static_assert(2 * NKS + 2 * RING <= 15, "LDS reads in flight");
+    const unsigned dza = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(dzimg + P * DZ_IMG + a_off);
+    const unsigned xba = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(ximg + P * X_IMG + b_off + tg * KHG * PXW * XB);
+    s16x4 alo[NKS], ahi[NKS], blo[RING], bhi[RING];
 #pragma unroll
-    for (int ks = 0; ks < PW / 16; ++ks) {
-      const bf16x8 fa = tr_frag((const u16*)(dzb + ks * 16 * DZB), (const u16*)(dzb + (ks * 16 + 4) * DZB));
-#pragma unroll
-      for (int r = 0; r < KHG; ++r)
-#pragma unroll
-        for (int s = 0; s < KH; ++s)
-#pragma unroll
-          for (int nt = 0; nt < NT; ++nt) {
-            const unsigned char* pb = xb + (((tg * KHG + r) * PXW + s + ks * 16 * STRIDE) * XB) + nt * 64;
-            const bf16x8 fb = tr_frag((const u16*)pb, (const u16*)(pb + 4 * STRIDE * XB));
-            acc[r * KH + s][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, fb, acc[r * KH + s][nt], 0, 0, 0);
-          }
+    for (int ks = 0; ks < NKS; ++ks) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[ks]) : "v"(dza), "n"(ks * 16 * DZB));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[ks]) : "v"(dza), "n"((ks * 16 + 4) * DZB));
     }
-    if (more) store_chunk(cur ^ 1);
-    __syncthreads();
+    auto boff = [](int i) constexpr -> int {
+      const int ks = i / NF, f = i % NF, r = f / (KH * NT), sx = (f / NT) % KH, nt = f % NT;
+      // k slice ks = 16 pixels: output row ks / 2 of the pair (STRIDE patch rows further down), columns 16 (ks % 2) ..
+      return ((r + (ks / 2) * STRIDE) * PXW + sx + (ks % 2) * 16 * STRIDE) * XB + nt * 64;
+    };
+#pragma unroll
+    for (int i = 0; i < RING; ++i) {
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(blo[i]) : "v"(xba), "n"(boff(i)));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(bhi[i]) : "v"(xba), "n"(boff(i) + 4 * STRIDE * XB));
+    }
+#pragma unroll
+    for (int i = 0; i < NTOT; ++i) {
+      constexpr int dummy = 0; (void)dummy;
+      const int younger = 2 * ((NTOT - 1 - i) < (RING - 1) ? (NTOT - 1 - i) : (RING - 1));
+      s16x4& lo = blo[i % RING];
+      s16x4& hi = bhi[i % RING];
+      // (the A fragments were requested in front of every B fragment: landed whenever a B fragment has)
+      // (tied only where a k slice starts: tied in every wait, hipcc copied them into fresh registers in front of every MFMA)
+      if (i % NF == 0) {
+        s16x4& a0 = alo[i / NF];
+        s16x4& a1 = ahi[i / NF];
+        asm volatile("" : "+v"(a0), "+v"(a1));
+      }
+      switch (younger) {
+        case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(lo), "+v"(hi)); break;
+        case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo), "+v"(hi)); break;
+        case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi)); break;
+        default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)); break;
+      }
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      const s16x8 av = __builtin_shufflevector(alo[i / NF], ahi[i / NF], 0, 1, 2, 3, 4, 5, 6, 7);
+      const s16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+      const int f = i % NF;
+#if CY_WG_DBG & 1
+      if (i == 0)
+#endif
+      acc[f / NT][f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&av, *(const bf16x8*)&bv, acc[f / NT][f % NT], 0, 0, 0);
+      if (i + RING < NTOT) {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(xba), "n"(boff(i + RING < NTOT ? i + RING : 0)));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(xba), "n"(boff(i + RING < NTOT ? i + RING : 0) + 4 * STRIDE * XB));
+      }
+    }
+    // set P (requested an iteration ago): only this iteration's NL loads are younger (one set: the loads of this iteration)
+    using SetC = std::integral_constant<int, NSET == 2 ? P : 0>;
+    wait_set(SetC{}, std::integral_constant<int, NSET == 2 ? NL : 0>{});
+    if (cid + 1 < c_hi) store_chunk(SetC{}, 1 - P);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  };
+  for (long long cid = c_lo; cid < c_hi; cid += 2) {
+    body(S0{}, cid);
+    if (cid + 1 < c_hi) body(S1{}, cid + 1);
   }
+  // phantom loads may still be in flight and hipcc does not know: their registers must not be reused before they have landed
+  wait_set(S0{}, N0{});
+  if constexpr (NSET == 2) wait_set(S1{}, N0{});
   // slab[split][co][ci][kh][kw]
   float* slab = a.slabs + (long long)split * a.Cout * a.Cin * TAPS;
   const int lcol = lane & 31, lh = lane >> 5;
@@ -1030,14 +1146,14 @@ inline int wg_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride,
   if (KH == 3 && p->wco != 4) return 1;             // instantiated: <3,1,4>, <4,2,4>, <4,2,2>
   p->ntiles_ci = Cin / p->ci_t;
   p->ntiles = (Cout / p->co_t) * p->ntiles_ci;
-  p->nchunk = (long long)B * Ho * ((Wo + 31) / 32);
+  p->nchunk = (long long)B * ((Ho + 1) / 2) * ((Wo + 31) / 32);        // chunks of 2 output rows x 32 pixels
   int ns = (512 / p->ntiles) & ~7;                  // about two rounds of blocks; a multiple of 8 (XCD grouping)
   if (ns < 8) ns = 8;
   while (ns > 8 && p->nchunk / ns < 8) ns -= 8;
   p->nsplit = ns;
   const int PXW = 31 * stride + KH;
   const int dzb = p->co_t * 2 + 64, xb = stride == 1 ? p->ci_t * 2 + 64 : (p->ci_t == 32 ? 96 : 160);
-  p->lds = (size_t)2 * (32 * dzb + KH * PXW * xb);
+  p->lds = (size_t)2 * (64 * dzb + (KH + stride) * PXW * xb);
   return 0;
 }
 
@@ -1057,6 +1173,8 @@ extern "C" int cy_conv_wgrad_bf16(const void* X, const void* dZ, float* dW, floa
              "cy_conv_wgrad_bf16: built for 3x3/s1 (Cout %% 128, Cin %% 64) and 4x4/s2 (Cout %% 64, Cin %% 32..64) with pad 1; got k=%d s=%d Cin=%d Cout=%d",
              KH, stride, Cin, Cout);
   CY_REQUIRE(Ho == (Hi + 2 - KH) / stride + 1 && Wo == (Wi + 2 - KH) / stride + 1, "cy_conv_wgrad_bf16: output size does not match pad 1");
+  CY_REQUIRE((long long)(Hi + 2) * (Wi + 2) * Cin * 2 < (1ll << 31) && (long long)Ho * Wo * Cout * 2 < (1ll << 31),
+             "cy_conv_wgrad_bf16: an image must stay below 2 GiB (32-bit buffer offsets; the offset 2^31 marks padding)");
   WgArgs a{(const u16*)X, (const u16*)dZ, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, p.nsplit, p.ntiles_ci, p.nchunk};
   hipStream_t s = (hipStream_t)stream;
   const unsigned grid = (unsigned)(p.ntiles * p.nsplit);
