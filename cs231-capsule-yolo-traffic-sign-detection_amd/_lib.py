@@ -125,6 +125,7 @@ _SIGS = {
     'cy_conv_gemm_bf16': [C.POINTER(ConvGemm), _I, _P],
     'cy_conv_gemm_bf16_classes': [C.POINTER(ConvGemm), _I, _I, _P],
     'cy_conv_wgrad_bf16': [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
+    'cy_conv_wgrad_bf16_bn': [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P],
     'cy_affine_act_bf16': [_P, _P, _P, _P, _F, _L, _I, _I, _P],
     'cy_bn_bwd_reduce_bf16': [_P, _P, _I, _P, _P, _P, _P, _F, _P, _L, _I, _P],
     'cy_bn_bwd_apply_bf16': [_P, _P, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _L, _I, _P],
@@ -140,6 +141,7 @@ _RET = {
     'cy_conv_packed_floats': (_L, [_I, _I]),
     'cy_conv_bf16_packed_elems': (_L, [_I, _I]),
     'cy_conv_wgrad_bf16_ws_floats': (_L, [_I, _I, _I, _I, _I, _I, _I]),
+    'cy_conv_wgrad_bf16_bn_ws_floats': (_L, [_I, _I, _I, _I, _I, _I, _I]),
     'cy_wino_packed_floats': (_L, [_I, _I]),
     'cy_wino_split_ws_floats': (_L, [_I, _I, _I, _I, _I, _I]),
     'cy_wino4_packed_floats': (_L, [_I, _I]),
@@ -163,7 +165,7 @@ _RET = {
     'cy_routing_fwd_ws_floats': (_L, [C.POINTER(RoutingFwd)]),
 }
 EXPORTS = sorted(list(_SIGS) + list(_RET))
-ABI_VERSION = 4     # what the signatures above were written against (include/capsyolo_hip.h, csrc/error.cpp)
+ABI_VERSION = 5     # what the signatures above were written against (include/capsyolo_hip.h, csrc/error.cpp)
 
 _lib = None
 

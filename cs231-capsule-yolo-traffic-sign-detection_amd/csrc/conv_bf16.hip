@@ -864,6 +864,11 @@ struct WgArgs {
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int nsplit, ntiles_ci;                            // grid: blockIdx.x = (s_hi * ntiles + tile) * 8 + s_lo
   long long nchunk;
+  // BNF (cy_conv_wgrad_bf16_bn): dZ holds the PREMASKED gradient d = dA * lrelu'(y) (what the consumer's input-gradient epilogue stored);
+  // dz = sc (d - m1 - (z - mu) is m2) -- cy_bn_bwd_apply_bf16's expression, so that the two paths agree bit for bit -- is formed
+  // between the load and the LDS store and written to dZout for the input-gradient kernel: the elementwise pass (18 GB at conv_2,
+  // 608 x 608) is gone.  bnc = [5][Cout]: sc, m1, mu, is, m2.
+  const u16* Z; u16* dZout; const float* bnc;
 };
 
 // developer knob for timing experiments (results are wrong when set): 1 one MFMA per chunk, 2 every load out of range (no memory traffic)
@@ -880,6 +885,10 @@ __device__ __forceinline__ void wg_load(u32x4_t& dst, wg_i32x4 desc, unsigned vo
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff));
 }
 
+__device__ __forceinline__ void wg_store(const u32x4_t& src, wg_i32x4 desc, unsigned voff, unsigned soff) {
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(src), "v"(voff), "s"(desc), "s"(soff) : "memory");
+}
+
 __device__ __forceinline__ bf16x8 tr_frag(const u16* p0, const u16* p1) {
   const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
   const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
@@ -893,7 +902,7 @@ __device__ __forceinline__ bf16x8 tr_frag(const u16* p0, const u16* p1) {
 // waves share a SIMD and one's LDS round trips (every MFMA needs a fresh transposed B fragment) run under the other's MFMAs.
 // 4x4 layers (16 taps, one 32-channel column per wave: 256 accumulator registers): the 8 waves are two TAP-ROW groups of
 // the 4-wave layout (TG = 2: kernel rows 0-1 / 2-3), 128 accumulator registers each.
-template <int KH, int STRIDE, int WCO, int NW = 4, int TG = 1>
+template <int KH, int STRIDE, int WCO, int NW = 4, int TG = 1, bool BNF = false>
 __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   constexpr int NTHR = 64 * NW;
   constexpr int WCI = NW / (WCO * TG), CO_T = 32 * WCO, CI_T = (KH == 3) ? 64 : 32 * (4 / WCO), CI_W = CI_T / WCI, NT = CI_W / 32;
@@ -910,6 +919,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* dzimg = smem_raw;                  // [2][DZ_IMG]
   unsigned char* ximg = smem_raw + 2 * DZ_IMG;      // [2][X_IMG]
+  float* bncs = (float*)(smem_raw + 2 * DZ_IMG + 2 * X_IMG);   // BNF: [5][CO_T]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int tg = wave / (WCO * WCI), wv = wave % (WCO * WCI);
@@ -939,10 +949,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   //    (the range check sees the vector offset only, so top / bottom rows are flagged like left / right columns);
   //  * a block whose chunk range has ended keeps loading PHANTOM chunks (num_records = 0): the loop issues the same NL loads in every
   //    iteration, and the wait in front of the LDS stores is the constant vmcnt(NL).
-  constexpr int NL = NDZ + NX;
+  constexpr int NL = (BNF ? 2 : 1) * NDZ + NX;
   constexpr int NSET = NL <= 5 ? 2 : 1;            // (conv_3's 64 x 64-channel tile stages 8 pieces per thread: two sets spill)
-  u32x4_t rdz[NSET][NDZ], rx[NSET][NX];
-  unsigned dzv[NDZ], xv[NX], xfl[NX];
+  u32x4_t rdz[NSET][NDZ], rx[NSET][NX], rzz[NSET][BNF ? NDZ : 1];
+  unsigned dzv[NDZ], xv[NX];
   int dzpx[NDZ], xjj[NX];                           // (packed: the column in bits 0..7, the row above)
 #pragma unroll
   for (int i = 0; i < NDZ; ++i) {
@@ -956,8 +966,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     const int c = t + NTHR * i;
     const int q = c % (CI_T / 8), pj = c / (CI_T / 8), j = pj % PXW, r = pj / PXW;
     xv[i] = c < X_CH ? (unsigned)(((r * a.Wi + j) * a.Cin + ci0 + q * 8) * 2) : 0x80000000u;
-    xjj[i] = j | (r << 8);                            // patch column, and from bit 8 on: patch row
-    xfl[i] = (r == 0 ? 1u : 0u) | (j == 0 ? 2u : 0u);
+    xjj[i] = j | (r << 8) | (r == 0 ? 1 << 16 : 0) | (j == 0 ? 2 << 16 : 0);   // patch column, row from bit 8, first-row / first-column flags from bit 16
   }
   const unsigned xshift = (unsigned)((a.Wi + 1) * a.Cin * 2);      // the X descriptor's base stands one row and one pixel in front of the image
   const unsigned ximg_b = (unsigned)(a.Hi * a.Wi * a.Cin * 2), zimg_b = (unsigned)(a.Ho * a.Wo * a.Cout * 2);
@@ -970,6 +979,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     coy = (int)(rr % RH) * PR; cb_ = (int)(rr / RH);
   }
   long long left = c_hi - c_lo;                     // real chunks not yet requested
+  const bool writer = BNF && (tile % a.ntiles_ci) == 0;          // the input-channel tiles of a dz tile all form it; the first one writes it
+  unsigned dzbad[NSET] = {};                        // BNF: items of the staged chunk that lie outside the image (their dz is zero, not kc)
+  wg_i32x4 ozd[NSET]; unsigned ozs[NSET] = {};
+  (void)writer;
   auto load_chunk = [&](auto set_c) {
     constexpr int S = decltype(set_c)::value;
     const int cw = ccw, oy = coy, b = cb_;
@@ -978,6 +991,8 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     --left;
     const int ox0 = cw * PW;
     const wg_i32x4 dzd = wg_desc(a.dZ + (long long)b * a.Ho * a.Wo * a.Cout, real ? zimg_b : 0u);
+    wg_i32x4 zzd = dzd;
+    if constexpr (BNF) zzd = wg_desc(a.Z + (long long)b * a.Ho * a.Wo * a.Cout, real ? zimg_b : 0u);
     const wg_i32x4 xd = wg_desc((const char*)(a.X + (long long)b * a.Hi * a.Wi * a.Cin) - xshift, real ? ximg_b + xshift : 0u);
     const unsigned zso = (unsigned)__builtin_amdgcn_readfirstlane(((oy * a.Wo + ox0) * a.Cout) * 2);
     const unsigned xso = (unsigned)__builtin_amdgcn_readfirstlane(((oy * STRIDE * a.Wi + ox0 * STRIDE) * a.Cin) * 2);
@@ -989,10 +1004,16 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     for (int i = 0; i < NDZ; ++i) {
       const bool bad = (CY_WG_DBG & 2) || (dzpx[i] & 255) >= zlim || (dzpx[i] >> 8) >= zrlim;
       wg_load(rdz[S][i], dzd, bad ? 0x80000000u : dzv[i], zso);
+      if constexpr (BNF) wg_load(rzz[S][i], zzd, bad ? 0x80000000u : dzv[i], zso);
+      if constexpr (BNF) dzbad[S] = (dzbad[S] & ~(1u << i)) | ((bad ? 1u : 0u) << i);
+    }
+    if constexpr (BNF) {                            // where this chunk's dz goes (stored when the set is); a phantom chunk or a block that shares the tile: nowhere
+      ozd[S] = wg_desc(a.dZout + (long long)b * a.Ho * a.Wo * a.Cout, (real && writer) ? zimg_b : 0u);
+      ozs[S] = zso;
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-      const bool bad = (CY_WG_DBG & 2) || (xfl[i] & bt) != 0u || (xjj[i] & 255) >= xlim || (xjj[i] >> 8) >= xrlim;
+      const bool bad = (CY_WG_DBG & 2) || (((unsigned)xjj[i] >> 16) & bt) != 0u || (xjj[i] & 255) >= xlim || ((xjj[i] >> 8) & 255) >= xrlim;
       wg_load(rx[S][i], xd, bad ? 0x80000000u : xv[i], xso);
     }
   };
@@ -1000,6 +1021,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     constexpr int S = decltype(set_c)::value, N = decltype(n_c)::value;
 #pragma unroll
     for (int i = 0; i < NDZ; ++i) { u32x4_t& r = rdz[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
+    if constexpr (BNF) {
+#pragma unroll
+      for (int i = 0; i < NDZ; ++i) { u32x4_t& r = rzz[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
+    }
 #pragma unroll
     for (int i = 0; i < NX; ++i) { u32x4_t& r = rx[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
   };
@@ -1009,7 +1034,21 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     for (int i = 0; i < NDZ; ++i) {
       const int c = t + NTHR * i;
       const int px = c / (CO_T / 8), q = c % (CO_T / 8);
-      if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = rdz[S][i];
+      if constexpr (BNF) {
+        float d[8], z[8], o[8];
+        unpack8(rdz[S][i], d);
+        unpack8(rzz[S][i], z);
+        const float* kc = bncs + q * 8;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+          o[k] = kc[k] * (d[k] - kc[CO_T + k] - ((z[k] - kc[2 * CO_T + k]) * kc[3 * CO_T + k]) * kc[4 * CO_T + k]);
+        u32x4_t ov = pack8(o);
+        if ((dzbad[S] >> i) & 1u) ov = u32x4_t{0u, 0u, 0u, 0u};       // outside the image: no pixel, no contribution
+        if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = ov;
+        wg_store(ov, ozd[S], ((dzbad[S] >> i) & 1u) ? 0x80000000u : dzv[i], ozs[S]);
+      } else {
+        if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = rdz[S][i];
+      }
     }
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
@@ -1026,6 +1065,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   const int a_off = (kh8 + q4) * DZB + (wco * 32 + cb * 16 + 4 * p4) * 2;                 // + ks * 16 * DZB (+ 4 * DZB)
   const int b_off = ((kh8 + q4) * STRIDE) * XB + (wci * CI_W + cb * 16 + 4 * p4) * 2;     // + tap / tile / ks terms
 
+  if constexpr (BNF) {
+    for (int i = t; i < 5 * CO_T; i += NTHR) bncs[i] = a.bnc[(i / CO_T) * a.Cout + co0 + i % CO_T];
+    __syncthreads();                                // (no load is in flight yet)
+  }
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
   using N0 = std::integral_constant<int, 0>;
@@ -1041,7 +1084,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     // Fragment reads as inline asm, the B fragments through a ring of three kept AHEAD of their MFMAs with counted waits: every MFMA needs
     // a fresh transposed B fragment, and left to hipcc each read stood right in front of its MFMA with its own wait (15 waits for 18
     // MFMAs; the ring holds three): an LDS round trip per MFMA and wave, which two waves per SIMD only half cover (mfma_busy 0.39).
-    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = 3;     // (2 NKS + 2 RING <= 15: lgkmcnt is a 4-bit counter)
+    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = BNF ? 2 : 3;     // (2 NKS + 2 RING <= 15: lgkmcnt is a 4-bit counter; BNF: registers)
     static_assert(2 * NKS + 2 * RING <= 15, "LDS reads in flight");
     const unsigned dza = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(dzimg + P * DZ_IMG + a_off);
     const unsigned xba = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(ximg + P * X_IMG + b_off + tg * KHG * PXW * XB);
@@ -1159,39 +1202,91 @@ inline int wg_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride,
 
 }  // namespace
 
+extern "C" long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride);
+namespace {
+// bnc[5][N]: sc, m1, mu, is, m2 of dz = sc (d - m1 - (z - mu) is m2)   (cy_bn_bwd_apply_bf16's constants, slope 1)
+__global__ void wgrad_bn_consts_kernel(const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                       const double* __restrict__ red, double inv_count, float* __restrict__ bnc, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  bnc[n] = scale[n];
+  bnc[N + n] = (float)(red[2 * n] * inv_count);
+  bnc[2 * N + n] = mean[n];
+  bnc[3 * N + n] = invstd[n];
+  bnc[4 * N + n] = (float)(red[2 * n + 1] * inv_count);
+}
+}  // namespace
+
+extern "C" long long cy_conv_wgrad_bf16_bn_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride) {
+  const long long n = cy_conv_wgrad_bf16_ws_floats(B, Ho, Wo, Cin, Cout, KH, stride);
+  return n < 0 ? n : n + 5ll * Cout;
+}
+
 extern "C" long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride) {
   WgPlan p;
   if (wg_plan(B, Ho, Wo, Cin, Cout, KH, stride, &p)) return -1;
   return (long long)p.nsplit * Cout * Cin * KH * KH;
 }
 
+static int wgrad_bf16_impl(const char* who, const void* X, const void* dZ, const void* Z, void* dZout, const float* bnc, float* dW, float* ws,
+                           int B, int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int stride, hipStream_t s) {
+  WgPlan p;
+  CY_REQUIRE(wg_plan(B, Ho, Wo, Cin, Cout, KH, stride, &p) == 0,
+             "%s: built for 3x3/s1 (Cout %% 128, Cin %% 64) and 4x4/s2 (Cout %% 64, Cin %% 32..64) with pad 1; got k=%d s=%d Cin=%d Cout=%d",
+             who, KH, stride, Cin, Cout);
+  CY_REQUIRE(Ho == (Hi + 2 - KH) / stride + 1 && Wo == (Wi + 2 - KH) / stride + 1, "%s: output size does not match pad 1", who);
+  CY_REQUIRE((long long)(Hi + 2) * (Wi + 2) * Cin * 2 < (1ll << 31) && (long long)Ho * Wo * Cout * 2 < (1ll << 31),
+             "%s: an image must stay below 2 GiB (32-bit buffer offsets; the offset 2^31 marks padding)", who);
+  WgArgs a{(const u16*)X, (const u16*)dZ, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, p.nsplit, p.ntiles_ci, p.nchunk, (const u16*)Z, (u16*)dZout, bnc};
+  const unsigned grid = (unsigned)(p.ntiles * p.nsplit);
+  const bool bnf = Z != nullptr;
+  const size_t lds = p.lds + (bnf ? (size_t)5 * p.co_t * 4 : 0);
+  int rc;
+#define CY_WG_LAUNCH(...)                                                                              \
+  do {                                                                                               \
+    if (bnf) { rc = cy_allow_lds(wgrad_bf16_kernel<__VA_ARGS__, true>, lds); if (rc) return rc;       \
+               wgrad_bf16_kernel<__VA_ARGS__, true><<<grid, 512, lds, s>>>(a); }                      \
+    else { rc = cy_allow_lds(wgrad_bf16_kernel<__VA_ARGS__, false>, lds); if (rc) return rc;          \
+           wgrad_bf16_kernel<__VA_ARGS__, false><<<grid, 512, lds, s>>>(a); }                         \
+  } while (0)
+  if (KH == 3) CY_WG_LAUNCH(3, 1, 4, 8, 1);
+  else if (p.wco == 4) CY_WG_LAUNCH(4, 2, 4, 8, 2);
+  else CY_WG_LAUNCH(4, 2, 2, 8, 2);
+#undef CY_WG_LAUNCH
+  CY_LAUNCH_CHECK(who);
+  const long long n = (long long)Cout * Cin * KH * KH;
+  wgrad_bf16_reduce_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, p.nsplit, n);
+  CY_LAUNCH_CHECK(who);
+  return 0;
+}
+
 extern "C" int cy_conv_wgrad_bf16(const void* X, const void* dZ, float* dW, float* ws, int B, int Hi, int Wi, int Cin, int Ho,
                                   int Wo, int Cout, int KH, int stride, void* stream) {
   CY_REQUIRE(X && dZ && dW && ws, "cy_conv_wgrad_bf16: null pointer");
-  WgPlan p;
-  CY_REQUIRE(wg_plan(B, Ho, Wo, Cin, Cout, KH, stride, &p) == 0,
-             "cy_conv_wgrad_bf16: built for 3x3/s1 (Cout %% 128, Cin %% 64) and 4x4/s2 (Cout %% 64, Cin %% 32..64) with pad 1; got k=%d s=%d Cin=%d Cout=%d",
-             KH, stride, Cin, Cout);
-  CY_REQUIRE(Ho == (Hi + 2 - KH) / stride + 1 && Wo == (Wi + 2 - KH) / stride + 1, "cy_conv_wgrad_bf16: output size does not match pad 1");
-  CY_REQUIRE((long long)(Hi + 2) * (Wi + 2) * Cin * 2 < (1ll << 31) && (long long)Ho * Wo * Cout * 2 < (1ll << 31),
-             "cy_conv_wgrad_bf16: an image must stay below 2 GiB (32-bit buffer offsets; the offset 2^31 marks padding)");
-  WgArgs a{(const u16*)X, (const u16*)dZ, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, p.nsplit, p.ntiles_ci, p.nchunk};
+  return wgrad_bf16_impl("cy_conv_wgrad_bf16", X, dZ, nullptr, nullptr, nullptr, dW, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, KH, stride,
+                         (hipStream_t)stream);
+}
+
+// The weight gradient with the block's BatchNorm backward (pass 2) on the way in: D = the premasked gradient dA * lrelu'(y) (bf16, what the
+// consumer's fused input-gradient epilogue stored), Z the block's raw convolution output; dz = scale (d - m1 - xhat m2) is written to dZ
+// (for the input-gradient kernel) and dW = its weight gradient; dgamma / dbeta from the sums `red` [N][2].  Replaces cy_bn_bwd_apply_bf16
+// (slope 1) + cy_conv_wgrad_bf16: dz comes out bit-identical.  ws: cy_conv_wgrad_bf16_bn_ws_floats().
+extern "C" int cy_conv_wgrad_bf16_bn(const void* X, const void* D, const void* Z, void* dZ, float* dW, float* ws, const float* scale,
+                                     const float* mean, const float* invstd, const double* red, float* dgamma, float* dbeta, int B,
+                                     int Hi, int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int stride, void* stream) {
+  CY_REQUIRE(X && D && Z && dZ && dW && ws && scale && mean && invstd && red, "cy_conv_wgrad_bf16_bn: null pointer");
+  CY_REQUIRE(dZ != D && dZ != Z, "cy_conv_wgrad_bf16_bn: dZ must not alias its inputs (several blocks read a tile that one of them writes)");
+  const long long base = cy_conv_wgrad_bf16_ws_floats(B, Ho, Wo, Cin, Cout, KH, stride);
+  CY_REQUIRE(base >= 0, "cy_conv_wgrad_bf16_bn: unsupported layer k=%d s=%d Cin=%d Cout=%d", KH, stride, Cin, Cout);
   hipStream_t s = (hipStream_t)stream;
-  const unsigned grid = (unsigned)(p.ntiles * p.nsplit);
-  int rc;
-  if (KH == 3) {
-    rc = cy_allow_lds(wgrad_bf16_kernel<3, 1, 4, 8>, p.lds); if (rc) return rc;
-    wgrad_bf16_kernel<3, 1, 4, 8><<<grid, 512, p.lds, s>>>(a);
-  } else if (p.wco == 4) {
-    rc = cy_allow_lds(wgrad_bf16_kernel<4, 2, 4, 8, 2>, p.lds); if (rc) return rc;
-    wgrad_bf16_kernel<4, 2, 4, 8, 2><<<grid, 512, p.lds, s>>>(a);
-  } else {
-    rc = cy_allow_lds(wgrad_bf16_kernel<4, 2, 2, 8, 2>, p.lds); if (rc) return rc;
-    wgrad_bf16_kernel<4, 2, 2, 8, 2><<<grid, 512, p.lds, s>>>(a);
+  float* bnc = ws + base;
+  wgrad_bn_consts_kernel<<<(Cout + 255) / 256, 256, 0, s>>>(scale, mean, invstd, red, 1.0 / ((double)B * Ho * Wo), bnc, Cout);
+  CY_LAUNCH_CHECK("cy_conv_wgrad_bf16_bn(constants)");
+  int rc = wgrad_bf16_impl("cy_conv_wgrad_bf16_bn", X, D, Z, dZ, bnc, dW, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, KH, stride, s);
+  if (rc) return rc;
+  if (dgamma && dbeta) {
+    bn_param_grad2_kernel<<<(Cout + 255) / 256, 256, 0, s>>>(red, dgamma, dbeta, Cout);
+    CY_LAUNCH_CHECK("cy_conv_wgrad_bf16_bn(param)");
   }
-  CY_LAUNCH_CHECK("cy_conv_wgrad_bf16");
-  const long long n = (long long)Cout * Cin * KH * KH;
-  wgrad_bf16_reduce_kernel<<<(unsigned)cy_ceil_div(n, 256), 256, 0, s>>>(ws, dW, p.nsplit, n);
-  CY_LAUNCH_CHECK("cy_conv_wgrad_bf16(reduce)");
   return 0;
 }

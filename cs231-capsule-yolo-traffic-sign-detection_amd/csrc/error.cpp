@@ -14,4 +14,4 @@ int cy_set_error(int code, const char* fmt, ...) {
 }
 
 extern "C" const char* capsyolo_last_error(void) { return g_err; }
-extern "C" int capsyolo_abi_version(void) { return 4; }
+extern "C" int capsyolo_abi_version(void) { return 5; }

@@ -127,6 +127,7 @@ def _x_geometry(x, nchw):
 
 STATS_COPIES = 16       # CY_STATS_COPIES of include/capsyolo_hip.h: BatchNorm statistics are accumulated in 16 striped copies
 USE_CONV1_MOMENTS = True  # ... whose BatchNorm statistics come from the 28 x 28 moment matrix of the input patches (csrc/conv1_moments.hip)
+FUSE_BN_BWD_APPLY_BF16 = True   # bf16 path: BatchNorm-backward pass 2 inside the weight gradient (cy_conv_wgrad_bf16_bn) where the gradient arrives premasked
 USE_CONV1_ONEPASS = True  # ... and whose backward then needs ONE pass over the gradient (cy_conv1_bn_bwd_onepass)
 CONV1_MOMENTS_MIN_PIXELS = 1 << 18   # ... from this many pixels on: below, its three launches cost more than the one recompute pass saves
 USE_CONV1_BWD = True     # ... and the backward of its whole conv -> BatchNorm -> LeakyReLU block without z / dz in memory
@@ -905,9 +906,21 @@ class _ConvBlockBF16(torch.autograd.Function):
             dist.all_reduce(red)
         dz = torch.empty_like(z)
         dgamma, dbeta = _empty((N,), weight), _empty((N,), weight)
-        call('cy_bn_bwd_apply_bf16', _ptr(z), _ptr(da), 1 if da_f32 else 0, _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean),
-             _ptr(invstd), slope, _ptr(red), _ptr(dgamma), _ptr(dbeta), P, N, st)
-        dW = conv_wgrad_bf16(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.name)
+        Bx, Hx, Wx, Cx = x.shape
+        nws = -1
+        if FUSE_BN_BWD_APPLY_BF16 and slope == 1.0 and not da_f32 and cfg.pad == 1:
+            # premasked gradient: BatchNorm-backward pass 2 inside the weight gradient's loader, dz written for the input gradient
+            nws = query('cy_conv_wgrad_bf16_bn_ws_floats', Bx, z.shape[1], z.shape[2], Cx, N, cfg.k, cfg.stride)
+        if nws >= 0:
+            ws = _empty((nws,), weight)
+            dW = _empty((N, Cx, cfg.k, cfg.k), weight)
+            with timer.range('conv_bf16_wgrad_bn/' + cfg.name):
+                call('cy_conv_wgrad_bf16_bn', _ptr(x), _ptr(da.contiguous()), _ptr(z), _ptr(dz), _ptr(dW), _ptr(ws), _ptr(scale), _ptr(mean),
+                     _ptr(invstd), _ptr(red), _ptr(dgamma), _ptr(dbeta), Bx, Hx, Wx, Cx, z.shape[1], z.shape[2], N, cfg.k, cfg.stride, st)
+        else:
+            call('cy_bn_bwd_apply_bf16', _ptr(z), _ptr(da), 1 if da_f32 else 0, _ptr(dz), _ptr(scale), _ptr(shift), _ptr(mean),
+                 _ptr(invstd), slope, _ptr(red), _ptr(dgamma), _ptr(dbeta), P, N, st)
+            dW = conv_wgrad_bf16(x, dz, cfg.k, cfg.stride, cfg.pad, cfg.name)
         dx = None
         if ctx.needs_input_grad[0]:
             in_f32 = bool(getattr(cfg, 'in_f32', False))

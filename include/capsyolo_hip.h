@@ -283,6 +283,15 @@ int cy_conv_gemm_bf16_classes(const cy_conv_gemm_t* a, int ncls, int out_f32, vo
 long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride);
 int cy_conv_wgrad_bf16(const void* X, const void* dZ, float* dW, float* ws, int B, int Hi, int Wi, int Cin, int Ho, int Wo,
                        int Cout, int KH, int stride, void* stream);
+/* ... with the block's BatchNorm backward (pass 2) on the way in (models.py:350-365 backward, "precision": "bf16"): D = the PREMASKED
+ * gradient dA * lrelu'(y) (bf16: what the consumer's fused input-gradient epilogue stored), Z = the block's raw convolution output;
+ * dz = scale (d - m1 - xhat m2) is written to dZ (bf16, for the input-gradient kernel; bit-identical to cy_bn_bwd_apply_bf16 with
+ * slope 1; must not alias D or Z), dW = its weight gradient, dgamma / dbeta (optional) from the sums red[N][2].
+ * ws: cy_conv_wgrad_bf16_bn_ws_floats() floats. */
+long long cy_conv_wgrad_bf16_bn_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride);
+int cy_conv_wgrad_bf16_bn(const void* X, const void* D, const void* Z, void* dZ, float* dW, float* ws, const float* scale,
+                          const float* mean, const float* invstd, const double* red, float* dgamma, float* dbeta, int B, int Hi,
+                          int Wi, int Cin, int Ho, int Wo, int Cout, int KH, int stride, void* stream);
 /* BatchNorm apply + LeakyReLU and the two backward passes on bf16 tensors (N divides 2048); dA may be fp32 (da_f32) */
 int cy_affine_act_bf16(const void* Z, void* A, const float* scale, const float* shift, float slope, long long P, int N,
                        int out_f32, void* stream);

@@ -251,6 +251,42 @@ def test_conv_bn_lrelu_block_bf16(case):
     assert int(hb.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize('case', BF16_CASES + [(3, 64, 33, 47, 128, 3, 1), (2, 256, 26, 26, 64, 4, 2)])
+def test_weight_gradient_with_the_batchnorm_backward_on_the_way_in(case):
+    """cy_conv_wgrad_bf16_bn (BatchNorm-backward pass 2 formed in the weight gradient's loader from the premasked gradient and z, dz
+    written out for the input-gradient kernel) against the two launches it replaces -- cy_bn_bwd_apply_bf16 with slope 1 and
+    cy_conv_wgrad_bf16: dz, dW, dgamma and dbeta BIT-IDENTICAL (the same expression per element, the same order of accumulation), on
+    every layer class incl. odd sizes and partial row pairs; run twice (no race between the blocks that share a dz tile)."""
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import call, query
+    B, Cin, H, W, Cout, k, s_ = case
+    Ho, Wo = (H + 2 - k) // s_ + 1, (W + 2 - k) // s_ + 1
+    nws = query('cy_conv_wgrad_bf16_bn_ws_floats', B, Ho, Wo, Cin, Cout, k, s_)
+    if nws < 0:
+        pytest.skip('layer class not built for the bf16 weight gradient')
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, H, W, Cin, generator=g).to(BF).to(dev())
+    d = torch.randn(B, Ho, Wo, Cout, generator=g).to(BF).to(dev())
+    z = torch.randn(B, Ho, Wo, Cout, generator=g).to(BF).to(dev())
+    sc = (torch.rand(Cout, generator=g) + 0.5).to(dev()); sh = torch.randn(Cout, generator=g).to(dev())
+    mu = (torch.randn(Cout, generator=g) * 0.2).to(dev()); isd = (torch.rand(Cout, generator=g) + 0.5).to(dev())
+    P = B * Ho * Wo
+    red = (torch.randn(Cout, 2, generator=g, dtype=torch.float64) * P * 0.01).to(dev())
+    st = torch.cuda.current_stream().cuda_stream
+    dz0 = torch.empty_like(z); dg0 = torch.empty(Cout, device=dev()); db0 = torch.empty(Cout, device=dev())
+    call('cy_bn_bwd_apply_bf16', z.data_ptr(), d.data_ptr(), 0, dz0.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1.0,
+         red.data_ptr(), dg0.data_ptr(), db0.data_ptr(), P, Cout, st)
+    dW0 = ops.conv_wgrad_bf16(x, dz0, k, s_, 1)
+    for rep in range(2):
+        dz1 = torch.full_like(z, float('nan')); dg1 = torch.empty(Cout, device=dev()); db1 = torch.empty(Cout, device=dev())
+        dW1 = torch.empty(Cout, Cin, k, k, device=dev()); ws = torch.empty(nws, device=dev())
+        call('cy_conv_wgrad_bf16_bn', x.data_ptr(), d.data_ptr(), z.data_ptr(), dz1.data_ptr(), dW1.data_ptr(), ws.data_ptr(), sc.data_ptr(),
+             mu.data_ptr(), isd.data_ptr(), red.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, k, s_, st)
+        assert torch.equal(dz1.view(torch.int16), dz0.view(torch.int16)), rep
+        assert torch.equal(dW1, dW0), (rep, float((dW1 - dW0).abs().max()))
+        assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
+
+
 def _oracle_bf16_forward(net, x, g):
     """The oracle's DarkCapsuleNet forward with the bf16 path's roundings restated on the CPU: block 1 with bf16 operands of its
     convolution, fp32 statistics and its activation rounded to bf16; blocks 2..5 with bf16 weights, fp32 accumulation, BatchNorm statistics from the fp32

@@ -27,7 +27,7 @@ def test_cabi_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), 'libcapsyolo_hip.so does not export %s' % name
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
-    assert lib.capsyolo_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.capsyolo_abi_version() == _lib.ABI_VERSION == 5
 
 
 def test_ctypes_structs_match_header_field_order():
