@@ -332,27 +332,69 @@ __global__ void length_bwd_kernel(const float* __restrict__ v, const float* __re
 // With few rows the row decomposition cannot fill the chip (R = 32 is one row tile), so the input capsules are split
 // over blocks as well: grid = (row tiles) x (chunks of i).  The sum over i then crosses blocks, which is a grid-wide
 // dependency once per routing iteration; on this chip a kernel boundary (~1.7 us) is cheaper than an in-kernel grid
-// barrier (5-7 us), so each iteration is one pass launch (routing_rows.hip) writing per-chunk partial sums plus a
-// finish (sum over chunks, squash, V += v).
-// forward finish of iteration `it` (s^t already summed over chunks into s_hist[it] by slab_sum_kernel):
-// v = squash(s), V (+)= v; thread <-> (row, j)
-template <int DOUT>
-__global__ void routing_fin_fwd_kernel(const float* __restrict__ s_hist_it, float* __restrict__ V,
-                                       float* __restrict__ v_out, int R, int C, int it, int last, int g, int B) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)R * C) return;
-  const int row = (int)(idx / C), j = (int)(idx - (long long)row * C);
-  const long long my = idx * DOUT;
-  float sv[DOUT], vv[DOUT];
+// barrier (5-7 us), so each iteration is one pass launch (routing_rows.hip) writing per-chunk partial sums plus ONE
+// finish launch (slab_fin_kernel: sum over chunks, squash, V += v).
+// slab_sum_kernel and the finish of an iteration in ONE launch (few rows: every launch boundary of the six-launch head costs ~2-5 us
+// next to 25 us of work): block = CPB = 64 / DOUT whole capsules x 16 slab phases; the partial sums are added in slab_sum_kernel's
+// order and the finish calls the same squash helpers on the gathered capsule vector, so the results equal the two-launch path's bit
+// for bit.  BWD = false: s_hist[it] = sum, v = squash(s), V (+)= v, last: v_out.  BWD = true: A_t = sum, SA += A_t,
+// ds_all[t - 1] = squash_bwd(s^{t-1}, SA).
+template <int DOUT, bool BWD>
+__global__ __launch_bounds__(1024) void slab_fin_kernel(const float* __restrict__ slabs, int nslabs, long long plane,
+                                                        float* __restrict__ s_hist_it, float* __restrict__ V, float* __restrict__ v_out,
+                                                        const float* __restrict__ s_prev, float* __restrict__ ds_prev, float* __restrict__ SA,
+                                                        int C, int it, int last, int g, int B) {
+  constexpr int CPB = 64 / DOUT, OPB = CPB * DOUT;
+  __shared__ float red[16][64];
+  __shared__ float sh[64], sh2[64];
+  const int lane = threadIdx.x & 63, ph = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * OPB + lane;
+  const bool act = lane < OPB && i < plane;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (act) {
+    int k = ph;
+    for (; k + 48 < nslabs; k += 64) {
+      s0 += slabs[(long long)k * plane + i];
+      s1 += slabs[(long long)(k + 16) * plane + i];
+      s2 += slabs[(long long)(k + 32) * plane + i];
+      s3 += slabs[(long long)(k + 48) * plane + i];
+    }
+    for (; k < nslabs; k += 16) s0 += slabs[(long long)k * plane + i];
+  }
+  red[ph][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph != 0) return;
+  float sum = 0.f;
 #pragma unroll
-  for (int o = 0; o < DOUT; ++o) sv[o] = s_hist_it[my + o];
-  squash_vec(sv, vv, DOUT);
+  for (int k = 0; k < 16; ++k) sum += red[k][lane];
+  const int cl = lane / DOUT, o = lane - cl * DOUT;     // capsule of the block, component
+  if constexpr (!BWD) {
+    if (act) s_hist_it[i] = sum;
+    sh[lane] = sum;
+    __builtin_amdgcn_s_waitcnt(0xC07F);                 // (one wave: LDS visibility is program order + lgkmcnt)
+    float sv[DOUT], vv[DOUT];
 #pragma unroll
-  for (int o = 0; o < DOUT; ++o) V[my + o] = (it == 0 ? 0.f : V[my + o]) + vv[o];
-  if (last) {
-    float* vo = v_out + (out_row(row, g, B) * C + j) * DOUT;
+    for (int q = 0; q < DOUT; ++q) sv[q] = sh[(cl < CPB ? cl : 0) * DOUT + q];
+    squash_vec(sv, vv, DOUT);
+    if (act) {
+      const float v = vv[o];
+      V[i] = (it == 0 ? 0.f : V[i]) + v;
+      if (last) {
+        const long long cap = i / DOUT;
+        const int row = (int)(cap / C), j = (int)(cap - (long long)row * C);
+        v_out[(out_row(row, g, B) * C + j) * DOUT + o] = v;
+      }
+    }
+  } else {
+    float sa = 0.f, sp = 0.f;
+    if (act) { sa = SA[i] + sum; SA[i] = sa; sp = s_prev[i]; }
+    sh[lane] = sp; sh2[lane] = sa;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    float sv[DOUT], dvv[DOUT], ds[DOUT];
 #pragma unroll
-    for (int o = 0; o < DOUT; ++o) vo[o] = vv[o];
+    for (int q = 0; q < DOUT; ++q) { sv[q] = sh[(cl < CPB ? cl : 0) * DOUT + q]; dvv[q] = sh2[(cl < CPB ? cl : 0) * DOUT + q]; }
+    squash_bwd_vec(sv, dvv, ds, DOUT);
+    if (act) ds_prev[i] = ds[o];
   }
 }
 
@@ -385,26 +427,6 @@ __global__ void routing_bwd_prep_kernel(const float* __restrict__ s_hist, const 
       for (int o = 0; o < DOUT; ++o) Vt[o] += vv[o];
     }
   }
-}
-
-// backward finish of step t (>= 1), A_t already summed over chunks into `At` by slab_sum_kernel:
-// SA += A_t ; ds_all[t-1] = squash_bwd(s^{t-1}, SA)
-template <int DOUT>
-__global__ void routing_bwd_fin_kernel(const float* __restrict__ At, const float* __restrict__ s_hist,
-                                       float* __restrict__ ds_all, float* __restrict__ SA, int R, int C, int t) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)R * C) return;
-  const long long plane = (long long)R * C * DOUT, my = idx * DOUT;
-  float sa[DOUT], sv[DOUT], ds[DOUT];
-#pragma unroll
-  for (int o = 0; o < DOUT; ++o) {
-    sa[o] = SA[my + o] + At[my + o];
-    SA[my + o] = sa[o];
-    sv[o] = s_hist[(long long)(t - 1) * plane + my + o];
-  }
-  squash_bwd_vec(sv, sa, ds, DOUT);
-#pragma unroll
-  for (int o = 0; o < DOUT; ++o) ds_all[(long long)(t - 1) * plane + my + o] = ds[o];
 }
 
 constexpr int C1_BLOCKS_DEFAULT = 256;     // one persistent block per CU
@@ -466,16 +488,16 @@ int launch_fwd(const cy_routing_fwd_t* a, hipStream_t s) {
   const long long plane = (long long)a->R * a->C * DOUT;
   float* V = a->ws + fwd_wp_floats(a->N, a->C, DOUT);
   float* slab = V + align4(plane);
-  const int fin_blocks = (int)cy_ceil_div((long long)a->R * a->C, 128);
   int nch = p.nch, ic = p.ic;
   if (mfma) mfma_chunks(a->R, a->N, p, &nch, &ic);
   for (int it = 0; it < a->n_iter; ++it) {
     r.fused = 0; r.it = it; r.ic = ic; r.V = it > 0 ? V : nullptr; r.slab = slab;
     rc = mfma ? cyi_mfma_launch(&r, nch, DOUT, s) : cyi_rows_launch(0, &r, &p, DOUT, s);
     if (rc) return rc;
-    slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, a->s_hist + (long long)it * plane, nch, plane);
-    routing_fin_fwd_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(a->s_hist + (long long)it * plane, V, a->v_out, a->R, a->C, it,
-                                                            it == a->n_iter - 1, a->gather_g, a->gather_B);
+    constexpr int OPB = (64 / DOUT) * DOUT;
+    slab_fin_kernel<DOUT, false><<<(unsigned)cy_ceil_div(plane, OPB), 1024, 0, s>>>(slab, nch, plane, a->s_hist + (long long)it * plane, V, a->v_out,
+                                                                                     nullptr, nullptr, nullptr, a->C, it, it == a->n_iter - 1,
+                                                                                     a->gather_g, a->gather_B);
   }
   return 0;
 }
@@ -513,8 +535,11 @@ int launch_bwd(const cy_routing_bwd_t* a, hipStream_t s) {
       r.fused = 0; r.it = t; r.ic = p.ic; r.V = V_all + (long long)t * plane; r.ds = ds_all + (long long)t * plane; r.slab = slab;
       rc = cyi_rows_launch(1, &r, &p, DOUT, s);
       if (rc) return rc;
-      slab_sum_kernel<<<(unsigned)cy_ceil_div(plane, 64), 1024, 0, s>>>(slab, At, p.nch, plane);
-      routing_bwd_fin_kernel<DOUT><<<fin_blocks, 128, 0, s>>>(At, a->s_hist, ds_all, SA, a->R, a->C, t);
+      constexpr int OPB = (64 / DOUT) * DOUT;
+      slab_fin_kernel<DOUT, true><<<(unsigned)cy_ceil_div(plane, OPB), 1024, 0, s>>>(slab, p.nch, plane, nullptr, nullptr, nullptr,
+                                                                                      a->s_hist + (long long)(t - 1) * plane,
+                                                                                      ds_all + (long long)(t - 1) * plane, SA, a->C, t, 0, 0, 1);
+      (void)At;
     }
   }
   return cyi_caps_bwd_launch(a, cdb, s);
