@@ -414,7 +414,10 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
 }
 
 // registers: (3 + MODE) arrays of NJ*DP floats per lane, plus ~60 for the read ring, u, addresses and the softmax
-constexpr int pick_wps(int dout, int nj, int mode) { return (3 + mode) * nj * rows_dp(dout) <= 200 ? 2 : 1; }
+#ifndef CY_ROWS_WPS_LIMIT
+#define CY_ROWS_WPS_LIMIT 200
+#endif
+constexpr int pick_wps(int dout, int nj, int mode) { return (3 + mode) * nj * rows_dp(dout) <= CY_ROWS_WPS_LIMIT ? 2 : 1; }
 
 template <int DOUT, int SLOTS, int NJ, int MODE>
 int launch_cfg(const cyi_rows_args_t* a, const cyi_rows_plan_t* p, hipStream_t s) {
