@@ -751,6 +751,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_bf16_kernel(const u16* __re
   }
 }
 
+__device__ __forceinline__ void bn_apply_consts(float sc, float mu, float is, double r0, double r1, double inv_count, float& ka, float& kb,
+                                                float& kc) {
+  const float m1 = (float)(r0 * inv_count), m2 = (float)(r1 * inv_count);
+  ka = sc;
+  kb = -sc * is * m2;
+  kc = sc * (mu * is * m2 - m1);
+}
+
 template <bool DA_F32>
 __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const u16* __restrict__ Z, const void* __restrict__ dA,
                                                                 u16* __restrict__ dZ, const float* __restrict__ scale,
@@ -761,12 +769,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const u16* __res
   const long long stride = (long long)gridDim.x * 256;
   long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const int c = (int)((i * 8) % N);
-  float sc[8], sh[8], mu[8], is[8], m1[8], m2[8];
+  // dz = sc (d - m1 - (z - mu) is m2) = d ka + z kb + kc: the three constants are formed ONCE per channel by bn_apply_consts (the same
+  // function in the fused weight gradient, cy_conv_wgrad_bf16_bn: the two paths agree bit for bit)
+  float sc[8], sh[8], ka[8], kb[8], kc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    sc[k] = scale[c + k]; sh[k] = shift[c + k]; mu[k] = mean[c + k]; is[k] = invstd[c + k];
-    m1[k] = (float)(red[2 * (c + k)] * inv_count);
-    m2[k] = (float)(red[2 * (c + k) + 1] * inv_count);
+    sc[k] = scale[c + k]; sh[k] = shift[c + k];
+    bn_apply_consts(sc[k], mean[c + k], invstd[c + k], red[2 * (c + k)], red[2 * (c + k) + 1], inv_count, ka[k], kb[k], kc[k]);
   }
   for (; i < n8; i += stride) {
     float z[8], g[8], o[8];
@@ -776,7 +785,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_bf16_kernel(const u16* __res
     for (int k = 0; k < 8; ++k) {
       const float y = z[k] * sc[k] + sh[k];
       const float d = y > 0.f ? g[k] : g[k] * slope;
-      o[k] = sc[k] * (d - m1[k] - ((z[k] - mu[k]) * is[k]) * m2[k]);
+      o[k] = __builtin_fmaf(d, ka[k], __builtin_fmaf(z[k], kb[k], kc[k]));
     }
     ((u32x4_t*)dZ)[i] = pack8(o);
   }
@@ -865,9 +874,9 @@ struct WgArgs {
   int nsplit, ntiles_ci;                            // grid: blockIdx.x = (s_hi * ntiles + tile) * 8 + s_lo
   long long nchunk;
   // BNF (cy_conv_wgrad_bf16_bn): dZ holds the PREMASKED gradient d = dA * lrelu'(y) (what the consumer's input-gradient epilogue stored);
-  // dz = sc (d - m1 - (z - mu) is m2) -- cy_bn_bwd_apply_bf16's expression, so that the two paths agree bit for bit -- is formed
+  // dz = sc (d - m1 - (z - mu) is m2) -- in cy_bn_bwd_apply_bf16's form d ka + z kb + kc, so that the two paths agree bit for bit -- is formed
   // between the load and the LDS store and written to dZout for the input-gradient kernel: the elementwise pass (18 GB at conv_2,
-  // 608 x 608) is gone.  bnc = [5][Cout]: sc, m1, mu, is, m2.
+  // 608 x 608) is gone.  bnc = [3][Cout]: ka, kb, kc of dz = d ka + z kb + kc.
   const u16* Z; u16* dZout; const float* bnc;
 };
 
@@ -919,7 +928,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned char* dzimg = smem_raw;                  // [2][DZ_IMG]
   unsigned char* ximg = smem_raw + 2 * DZ_IMG;      // [2][X_IMG]
-  float* bncs = (float*)(smem_raw + 2 * DZ_IMG + 2 * X_IMG);   // BNF: [5][CO_T]
+  float* bncs = (float*)(smem_raw + 2 * DZ_IMG + 2 * X_IMG);   // BNF: [3][CO_T]
+  // BNF: z of the staged chunk comes in by LDS-DMA, every lane's 16 bytes at its item index (it reads back what it requested: no
+  // layout, no barrier): in registers it cost a second register file of staging and left ONE set -- no prefetch beyond the chunk
+  unsigned char* zlds = smem_raw + 2 * DZ_IMG + 2 * X_IMG + 3 * CO_T * 4;   // [NSET][NDZ * NTHR * 16]
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int tg = wave / (WCO * WCI), wv = wave % (WCO * WCI);
@@ -949,9 +961,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   //    (the range check sees the vector offset only, so top / bottom rows are flagged like left / right columns);
   //  * a block whose chunk range has ended keeps loading PHANTOM chunks (num_records = 0): the loop issues the same NL loads in every
   //    iteration, and the wait in front of the LDS stores is the constant vmcnt(NL).
-  constexpr int NL = (BNF ? 2 : 1) * NDZ + NX;
-  constexpr int NSET = NL <= 5 ? 2 : 1;            // (conv_3's 64 x 64-channel tile stages 8 pieces per thread: two sets spill)
-  u32x4_t rdz[NSET][NDZ], rx[NSET][NX], rzz[NSET][BNF ? NDZ : 1];
+  constexpr int NL = (BNF ? 2 : 1) * NDZ + NX;     // vector-memory operations per staged chunk (BNF: + the z DMAs)
+  constexpr int NSET = NDZ + NX <= 5 ? 2 : 1;            // (conv_3's 64 x 64-channel tile stages 8 pieces per thread: two sets spill)
+  u32x4_t rdz[NSET][NDZ], rx[NSET][NX];
   unsigned dzv[NDZ], xv[NX];
   int dzpx[NDZ], xjj[NX];                           // (packed: the column in bits 0..7, the row above)
 #pragma unroll
@@ -1004,7 +1016,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     for (int i = 0; i < NDZ; ++i) {
       const bool bad = (CY_WG_DBG & 2) || (dzpx[i] & 255) >= zlim || (dzpx[i] >> 8) >= zrlim;
       wg_load(rdz[S][i], dzd, bad ? 0x80000000u : dzv[i], zso);
-      if constexpr (BNF) wg_load(rzz[S][i], zzd, bad ? 0x80000000u : dzv[i], zso);
+      if constexpr (BNF) {
+        const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(zlds + (S * NDZ + i) * NTHR * 16) + wave * 1024);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" : : "v"(bad ? 0x80000000u : dzv[i]), "s"(zzd), "s"(m0v), "s"(zso) : "memory");
+      }
       if constexpr (BNF) dzbad[S] = (dzbad[S] & ~(1u << i)) | ((bad ? 1u : 0u) << i);
     }
     if constexpr (BNF) {                            // where this chunk's dz goes (stored when the set is); a phantom chunk or a block that shares the tile: nowhere
@@ -1021,10 +1036,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     constexpr int S = decltype(set_c)::value, N = decltype(n_c)::value;
 #pragma unroll
     for (int i = 0; i < NDZ; ++i) { u32x4_t& r = rdz[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
-    if constexpr (BNF) {
-#pragma unroll
-      for (int i = 0; i < NDZ; ++i) { u32x4_t& r = rzz[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
-    }
+    asm volatile("" ::: "memory");                  // (BNF: the z DMAs of the set have landed with its loads: they are older than its x loads)
 #pragma unroll
     for (int i = 0; i < NX; ++i) { u32x4_t& r = rx[S][i]; asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r) : "n"(N)); }
   };
@@ -1037,11 +1049,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
       if constexpr (BNF) {
         float d[8], z[8], o[8];
         unpack8(rdz[S][i], d);
-        unpack8(rzz[S][i], z);
+        unpack8(*(const u32x4_t*)(zlds + ((S * NDZ + i) * NTHR + t) * 16), z);
         const float* kc = bncs + q * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-          o[k] = kc[k] * (d[k] - kc[CO_T + k] - ((z[k] - kc[2 * CO_T + k]) * kc[3 * CO_T + k]) * kc[4 * CO_T + k]);
+        for (int k = 0; k < 8; ++k) o[k] = __builtin_fmaf(d[k], kc[k], __builtin_fmaf(z[k], kc[CO_T + k], kc[2 * CO_T + k]));
         u32x4_t ov = pack8(o);
         if ((dzbad[S] >> i) & 1u) ov = u32x4_t{0u, 0u, 0u, 0u};       // outside the image: no pixel, no contribution
         if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = ov;
@@ -1066,7 +1077,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   const int b_off = ((kh8 + q4) * STRIDE) * XB + (wci * CI_W + cb * 16 + 4 * p4) * 2;     // + tap / tile / ks terms
 
   if constexpr (BNF) {
-    for (int i = t; i < 5 * CO_T; i += NTHR) bncs[i] = a.bnc[(i / CO_T) * a.Cout + co0 + i % CO_T];
+    for (int i = t; i < 3 * CO_T; i += NTHR) bncs[i] = a.bnc[(i / CO_T) * a.Cout + co0 + i % CO_T];
     __syncthreads();                                // (no load is in flight yet)
   }
   using S0 = std::integral_constant<int, 0>;
@@ -1084,13 +1095,16 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     // Fragment reads as inline asm, the B fragments through a ring of three kept AHEAD of their MFMAs with counted waits: every MFMA needs
     // a fresh transposed B fragment, and left to hipcc each read stood right in front of its MFMA with its own wait (15 waits for 18
     // MFMAs; the ring holds three): an LDS round trip per MFMA and wave, which two waves per SIMD only half cover (mfma_busy 0.39).
-    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = BNF ? 2 : 3;     // (2 NKS + 2 RING <= 15: lgkmcnt is a 4-bit counter; BNF: registers)
-    static_assert(2 * NKS + 2 * RING <= 15, "LDS reads in flight");
+    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = 3, ASL = 2;      // (2 ASL + 2 RING + 2 <= 15: lgkmcnt is a 4-bit counter)
+    static_assert(2 * ASL + 2 * RING + 2 <= 15 && NF > RING && NKS % ASL == 0, "LDS reads in flight");
     const unsigned dza = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(dzimg + P * DZ_IMG + a_off);
     const unsigned xba = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(ximg + P * X_IMG + b_off + tg * KHG * PXW * XB);
-    s16x4 alo[NKS], ahi[NKS], blo[RING], bhi[RING];
+    // the A fragments of TWO k slices at a time (all four up front were 16 registers): slice ks + 2 is requested into slice ks's pair
+    // behind that slice's last MFMA -- younger than the B fragments in flight then, so the counted waits in front of those only wait
+    // for more than they need, and NF MFMAs older than its own first use
+    s16x4 alo[ASL], ahi[ASL], blo[RING], bhi[RING];
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
+    for (int ks = 0; ks < ASL; ++ks) {
       asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(alo[ks]) : "v"(dza), "n"(ks * 16 * DZB));
       asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(ahi[ks]) : "v"(dza), "n"((ks * 16 + 4) * DZB));
     }
@@ -1113,8 +1127,8 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
       // (the A fragments were requested in front of every B fragment: landed whenever a B fragment has)
       // (tied only where a k slice starts: tied in every wait, hipcc copied them into fresh registers in front of every MFMA)
       if (i % NF == 0) {
-        s16x4& a0 = alo[i / NF];
-        s16x4& a1 = ahi[i / NF];
+        s16x4& a0 = alo[(i / NF) % ASL];
+        s16x4& a1 = ahi[(i / NF) % ASL];
         asm volatile("" : "+v"(a0), "+v"(a1));
       }
       switch (younger) {
@@ -1124,13 +1138,20 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
         default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi)); break;
       }
       typedef short s16x8 __attribute__((ext_vector_type(8)));
-      const s16x8 av = __builtin_shufflevector(alo[i / NF], ahi[i / NF], 0, 1, 2, 3, 4, 5, 6, 7);
+      const s16x8 av = __builtin_shufflevector(alo[(i / NF) % ASL], ahi[(i / NF) % ASL], 0, 1, 2, 3, 4, 5, 6, 7);
       const s16x8 bv = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
       const int f = i % NF;
 #if CY_WG_DBG & 1
       if (i == 0)
 #endif
       acc[f / NT][f % NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const bf16x8*)&av, *(const bf16x8*)&bv, acc[f / NT][f % NT], 0, 0, 0);
+      if (i % NF == NF - 1 && i / NF + ASL < NKS) {     // the slice's last MFMA is issued: its A pair takes slice ks + ASL
+        constexpr int dummy2 = 0; (void)dummy2;
+        s16x4& a0 = alo[(i / NF) % ASL];
+        s16x4& a1 = ahi[(i / NF) % ASL];
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a0) : "v"(dza), "n"((i / NF + ASL < NKS ? i / NF + ASL : 0) * 16 * DZB));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(a1) : "v"(dza), "n"(((i / NF + ASL < NKS ? i / NF + ASL : 0) * 16 + 4) * DZB));
+      }
       if (i + RING < NTOT) {
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(xba), "n"(boff(i + RING < NTOT ? i + RING : 0)));
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(xba), "n"(boff(i + RING < NTOT ? i + RING : 0) + 4 * STRIDE * XB));
@@ -1204,22 +1225,18 @@ inline int wg_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride,
 
 extern "C" long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride);
 namespace {
-// bnc[5][N]: sc, m1, mu, is, m2 of dz = sc (d - m1 - (z - mu) is m2)   (cy_bn_bwd_apply_bf16's constants, slope 1)
+// bnc[3][N]: ka, kb, kc of dz = d ka + z kb + kc   (bn_apply_consts: cy_bn_bwd_apply_bf16's constants, slope 1)
 __global__ void wgrad_bn_consts_kernel(const float* __restrict__ scale, const float* __restrict__ mean, const float* __restrict__ invstd,
                                        const double* __restrict__ red, double inv_count, float* __restrict__ bnc, int N) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
-  bnc[n] = scale[n];
-  bnc[N + n] = (float)(red[2 * n] * inv_count);
-  bnc[2 * N + n] = mean[n];
-  bnc[3 * N + n] = invstd[n];
-  bnc[4 * N + n] = (float)(red[2 * n + 1] * inv_count);
+  bn_apply_consts(scale[n], mean[n], invstd[n], red[2 * n], red[2 * n + 1], inv_count, bnc[n], bnc[N + n], bnc[2 * N + n]);
 }
 }  // namespace
 
 extern "C" long long cy_conv_wgrad_bf16_bn_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride) {
   const long long n = cy_conv_wgrad_bf16_ws_floats(B, Ho, Wo, Cin, Cout, KH, stride);
-  return n < 0 ? n : n + 5ll * Cout;
+  return n < 0 ? n : n + 3ll * Cout;
 }
 
 extern "C" long long cy_conv_wgrad_bf16_ws_floats(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride) {
@@ -1240,7 +1257,9 @@ static int wgrad_bf16_impl(const char* who, const void* X, const void* dZ, const
   WgArgs a{(const u16*)X, (const u16*)dZ, ws, B, Hi, Wi, Cin, Ho, Wo, Cout, p.nsplit, p.ntiles_ci, p.nchunk, (const u16*)Z, (u16*)dZout, bnc};
   const unsigned grid = (unsigned)(p.ntiles * p.nsplit);
   const bool bnf = Z != nullptr;
-  const size_t lds = p.lds + (bnf ? (size_t)5 * p.co_t * 4 : 0);
+  // BNF: + the constants and the z staging (one 16-byte piece per dz item and register set: wgrad_bf16_kernel's NDZ, NX, NSET)
+  const int ndz = (64 * (p.co_t / 8) + 511) / 512, nx = ((KH + stride) * (31 * stride + KH) * (p.ci_t / 8) + 511) / 512;
+  const size_t lds = p.lds + (bnf ? (size_t)3 * p.co_t * 4 + (size_t)(ndz + nx <= 5 ? 2 : 1) * ndz * 512 * 16 : 0);
   int rc;
 #define CY_WG_LAUNCH(...)                                                                              \
   do {                                                                                               \
