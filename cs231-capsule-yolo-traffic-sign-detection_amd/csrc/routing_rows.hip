@@ -183,9 +183,16 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
       // ONE wave per SIMD (WPS = 1): four reads per wait -- a tied wait is an issue slot, and hipcc pads a wait state (s_nop, another slot)
       // between an asm statement that defines vector registers and the next vector instruction (whatever stands in between): per
       // float4 that was 5 slots for 2 packed FMAs (DarkCapsuleNet3 head, row part of the backward: 5.5 -> 4.9 ms with pairs).  Two waves per SIMD fill each other's
-      // slots: there the finer wait is the better one (the same head's forward: 3.6 ms against 3.7 with pairs).
-      constexpr int ST = WPS == 1 ? 4 : 1;              // reads per tied wait
-      constexpr int PF = (DD4 < 4 + ST) ? DD4 : 4 + ST; // reads in flight
+      // slots: there pairs with only FOUR reads in flight are the best of the grid (reads per wait, reads in flight) = (1,3) 3.69, (1,4) 3.58,
+      // (1,5) 3.58, (2,4) **3.45**, (2,6) 3.91, (2,8) 4.32 ms on the same head's forward: deeper rings cost registers at 256 per wave.
+#ifndef CY_ROWS_ST2
+#define CY_ROWS_ST2 2
+#endif
+#ifndef CY_ROWS_PF2
+#define CY_ROWS_PF2 4
+#endif
+      constexpr int ST = WPS == 1 ? 4 : CY_ROWS_ST2;    // reads per tied wait
+      constexpr int PF = WPS == 1 ? ((DD4 < 4 + ST) ? DD4 : 4 + ST) : ((DD4 < CY_ROWS_PF2) ? DD4 : CY_ROWS_PF2); // reads in flight
       static_assert(DD4 % 4 == 0 && PF % ST == 0, "the W image is read in groups of four float4");
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
@@ -207,6 +214,14 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
             switch (younger) {
               case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
               default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
+            }
+          } else if constexpr (ST == 2) {
+            f32x4& w1 = wq[(q + 1) % PF];
+            switch (younger) {
+              case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(w0), "+v"(w1)); break;
+              case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1)); break;
+              case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(w0), "+v"(w1)); break;
+              default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1)); break;
             }
           } else {
             switch (younger) {
