@@ -26,6 +26,25 @@ namespace {
 // SAVED: the row part (routing_rows.hip, fused plans) left c^t and db^t of every (t >= 1, row, i, j) in `cdb`
 // ([t - 1][row][i][2][C]): this kernel then recomputes neither u_hat (a pass over W_i) nor the logits and the softmax (two
 // dot products over Dout and three wavefront reductions per iteration) -- 250 instead of 560 vector instructions per (row, i).
+// tied wait for ST (2 or 4) float4 of the W ring: all but the `younger` youngest LDS reads have landed
+template <int ST>
+__device__ __forceinline__ void caps_wait(int younger, f32x4& a, f32x4& b, f32x4& c, f32x4& d) {
+  if constexpr (ST == 4) {
+    switch (younger) {
+      case 12: asm volatile("s_waitcnt lgkmcnt(12)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); break;
+      case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); break;
+      case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); break;
+      default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)); break;
+    }
+  } else {
+    switch (younger) {
+      case 6: asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(a), "+v"(b)); break;
+      case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(a), "+v"(b)); break;
+      case 2: asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(a), "+v"(b)); break;
+      default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); break;
+    }
+  }
+}
 constexpr int CDB_TMAX = 4;                         // iterations t >= 1 whose couplings a lane prefetches (n_iter <= 5)
 // NTT: the number of routing iterations as a compile-time constant (3: every head of the reference's models), 0 = read from the arguments.
 // With it the loops over the row's vectors and over the iterations unroll, their 64-bit offsets become loop invariants and the
@@ -192,8 +211,14 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
   const unsigned wa = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const float*)(Wme + jl * WS);
   // reads of the W image per tied wait and in flight (routing_rows.hip: a tied wait and the wait state hipcc pads behind it are issue
   // slots; up to four waves a wave has 512 registers for the deeper ring, the six-wave variants spill as it is)
-  constexpr int ST = G <= 4 ? 4 : 2;
-  constexpr int PF = 2 * ST;
+#ifndef CY_CAPS_ST
+#define CY_CAPS_ST 4
+#endif
+#ifndef CY_CAPS_PF
+#define CY_CAPS_PF 8
+#endif
+  constexpr int ST = G <= 4 ? CY_CAPS_ST : 2;
+  constexpr int PF = G <= 4 ? CY_CAPS_PF : 4;
   static_assert(DD4 % ST == 0 && DD4 >= PF, "the W image is read in groups of ST float4");
 
   // pair h of a Dout-vector in LDS (4-byte aligned: ds_read2_b32); the pad component of an odd Dout reads as 0
@@ -231,14 +256,9 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
       for (int p = 0; p < PF; ++p) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[p]) : "v"(wa), "n"(16 * p));
 #pragma unroll
       for (int q = 0; q < DD4; q += ST) {             // ST reads per tied wait
-        const bool more = q + PF <= DD4;              // a whole group is still in flight behind this one
-        if constexpr (ST == 4) {
-          if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]), "+v"(wq[(q + 2) % PF]), "+v"(wq[(q + 3) % PF]));
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]), "+v"(wq[(q + 2) % PF]), "+v"(wq[(q + 3) % PF]));
-        } else {
-          if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]));
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[q % PF]), "+v"(wq[(q + 1) % PF]));
-        }
+        constexpr int dummyq = 0; (void)dummyq;
+        const int younger = (q + PF <= DD4 ? PF : DD4 - q) - ST;      // reads in flight behind this group
+        caps_wait<ST>(younger, wq[q % PF], wq[(q + 1) % PF], wq[(q + 2 < DD4 ? q + 2 : q) % PF], wq[(q + 3 < DD4 ? q + 3 : q) % PF]);
 #pragma unroll
         for (int e = 0; e < 2 * ST; ++e) {
           const int f = 4 * q + 2 * e, d = f / DP, h = (f % DP) / 2;
@@ -345,14 +365,8 @@ __global__ __launch_bounds__(64 * G, 1) void caps_bwd_kernel(cy_routing_bwd_t a,
       for (int pq = 0; pq < PF; ++pq) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wq[pq]) : "v"(wa), "n"(16 * qord(pq)));
 #pragma unroll
       for (int k = 0; k < DD4; k += ST) {
-        const bool more = k + PF <= DD4;
-        if constexpr (ST == 4) {
-          if (more) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]), "+v"(wq[(k + 2) % PF]), "+v"(wq[(k + 3) % PF]));
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]), "+v"(wq[(k + 2) % PF]), "+v"(wq[(k + 3) % PF]));
-        } else {
-          if (more) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]));
-          else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(wq[k % PF]), "+v"(wq[(k + 1) % PF]));
-        }
+        const int younger = (k + PF <= DD4 ? PF : DD4 - k) - ST;
+        caps_wait<ST>(younger, wq[k % PF], wq[(k + 1) % PF], wq[(k + 2 < DD4 ? k + 2 : k) % PF], wq[(k + 3 < DD4 ? k + 3 : k) % PF]);
 #pragma unroll
         for (int e = 0; e < 2; ++e)
 #pragma unroll

@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
 #define CY_ROWS_PF2 4
 #endif
       constexpr int ST = WPS == 1 ? 4 : CY_ROWS_ST2;    // reads per tied wait
-      constexpr int PF = WPS == 1 ? ((DD4 < 4 + ST) ? DD4 : 4 + ST) : ((DD4 < CY_ROWS_PF2) ? DD4 : CY_ROWS_PF2); // reads in flight
+#ifndef CY_ROWS_PF1
+#define CY_ROWS_PF1 8
+#endif
+      constexpr int PF = WPS == 1 ? ((DD4 < CY_ROWS_PF1) ? DD4 : CY_ROWS_PF1) : ((DD4 < CY_ROWS_PF2) ? DD4 : CY_ROWS_PF2); // reads in flight
       static_assert(DD4 % 4 == 0 && PF % ST == 0, "the W image is read in groups of four float4");
 #pragma unroll
       for (int k = 0; k < NJ; ++k) {
@@ -212,6 +215,7 @@ __global__ __launch_bounds__(256 * WPS, 1) void caps_rows_kernel(cyi_rows_args_t
             f32x4& w2 = wq[(q + 2) % PF];
             f32x4& w3 = wq[(q + 3) % PF];
             switch (younger) {
+              case 8: asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
               case 4: asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
               default: asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(w0), "+v"(w1), "+v"(w2), "+v"(w3)); break;
             }
