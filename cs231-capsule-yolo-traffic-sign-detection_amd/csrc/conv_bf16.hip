@@ -884,6 +884,9 @@ struct WgArgs {
 #ifndef CY_WG_DBG
 #define CY_WG_DBG 0
 #endif
+#ifndef CY_WG_RING
+#define CY_WG_RING 3               // B fragments in flight ahead of their MFMAs (swept 2 / 3 / 4)
+#endif
 typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ wg_i32x4 wg_desc(const void* p, unsigned bytes) {
   const unsigned long long b = (unsigned long long)(uintptr_t)p;
@@ -1095,7 +1098,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     // Fragment reads as inline asm, the B fragments through a ring of three kept AHEAD of their MFMAs with counted waits: every MFMA needs
     // a fresh transposed B fragment, and left to hipcc each read stood right in front of its MFMA with its own wait (15 waits for 18
     // MFMAs; the ring holds three): an LDS round trip per MFMA and wave, which two waves per SIMD only half cover (mfma_busy 0.39).
-    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = 3, ASL = 2;      // (2 ASL + 2 RING + 2 <= 15: lgkmcnt is a 4-bit counter)
+    constexpr int NF = KHG * KH * NT, NKS = PIX / 16, NTOT = NKS * NF, RING = CY_WG_RING, ASL = 2;      // (2 ASL + 2 RING + 2 <= 15: lgkmcnt is a 4-bit counter)
     static_assert(2 * ASL + 2 * RING + 2 <= 15 && NF > RING && NKS % ASL == 0, "LDS reads in flight");
     const unsigned dza = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(dzimg + P * DZ_IMG + a_off);
     const unsigned xba = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const unsigned char*)(ximg + P * X_IMG + b_off + tg * KHG * PXW * XB);
@@ -1211,7 +1214,13 @@ inline int wg_plan(int B, int Ho, int Wo, int Cin, int Cout, int KH, int stride,
   p->ntiles_ci = Cin / p->ci_t;
   p->ntiles = (Cout / p->co_t) * p->ntiles_ci;
   p->nchunk = (long long)B * ((Ho + 1) / 2) * ((Wo + 31) / 32);        // chunks of 2 output rows x 32 pixels
-  int ns = (512 / p->ntiles) & ~7;                  // about two rounds of blocks; a multiple of 8 (XCD grouping)
+  // ONE round of blocks (a multiple of 8: XCD grouping): every block ends with its whole accumulator tile going to a slab (295 KB at
+  // conv_2) that the reduce kernel reads back -- swept 256 / 512 / 768 / 1024 blocks: conv_4 / conv_5 0.29 / 0.38 / 0.46 / 0.56 ms,
+  // conv_3 1.97 / 2.03 / 2.09 / 2.17, conv_2 6.08 / 6.14 / 6.16 / 6.23
+  int ns = (256 / p->ntiles) & ~7;
+#ifdef CY_WG_ENV
+  if (const char* e = getenv("CY_WG_NS")) ns = (atoi(e) / p->ntiles) & ~7;   // developer sweep of the block count (builds with -DCY_WG_ENV only)
+#endif
   if (ns < 8) ns = 8;
   while (ns > 8 && p->nchunk / ns < 8) ns -= 8;
   p->nsplit = ns;
