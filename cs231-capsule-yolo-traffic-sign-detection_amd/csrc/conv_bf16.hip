@@ -194,7 +194,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
   // the K loops.  The blocks of an XCD therefore start an eighth of a tile apart (one sleep of ~0.2 us per K step and phase).
   if (gridDim.x >= 64) {
     const int phase = (blockIdx.x >> 3) & 7;
+#ifndef CY_BF_NOSTAGGER
     for (int i = 0; i < phase * (KT + 6); ++i) __builtin_amdgcn_s_sleep(8);
+#endif
   }
   int cur = 0, slot = 0;
   // Consecutive tiles are consecutive pixel segments: the rows a 3 x 3 tap reads above and below a tile are the rows of the next
@@ -232,7 +234,10 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 1 : 2) void conv_bf1
       // itself hipcc (at 237 registers) reuses ONE register quad for all A fragments and waits lgkmcnt(0) behind every
       // read -- four exposed LDS round trips per slice, 60 % of the step.
       const unsigned lbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem_raw + cur * BUF_BYTES;
-      constexpr int PPG = (NA + NB + 1) / 2;                              // DMA pieces per MFMA group: all in the first two groups (a piece issued late in the step is waited for at the top of the next)
+#ifndef CY_BF_PPG_DIV
+#define CY_BF_PPG_DIV 2           // the K step's DMA pieces are issued behind the first CY_BF_PPG_DIV of its four MFMA groups (swept 1 / 2 / 4)
+#endif
+      constexpr int PPG = (NA + NB + CY_BF_PPG_DIV - 1) / CY_BF_PPG_DIV;                              // DMA pieces per MFMA group: all in the first two groups (a piece issued late in the step is waited for at the top of the next)
       u32x4_t fa[2][MI], fb[2][NI];
       auto issue = [&](int ks, int set) {
         const unsigned aa = lbase + a_row + xoff[ks], ba = lbase + b_row + xoff[ks];
