@@ -287,6 +287,56 @@ def test_weight_gradient_with_the_batchnorm_backward_on_the_way_in(case):
         assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
 
 
+def test_weight_gradient_bf16_random_shapes():
+    """Seeded random shapes (odd sizes, one-row and one-segment images, partial row pairs, every layer class) through the bf16 weight
+    gradient's hand-waited loader -- border flags, two output rows per chunk, phantom chunks behind a block's range -- plain against
+    torch fp64 and run to run, and fused with the BatchNorm backward against the two launches it replaces (bit-identical)."""
+    import random
+    from capsyolo_amd import ops
+    from capsyolo_amd._lib import call, query
+    rng = random.Random(2024)
+    st = torch.cuda.current_stream().cuda_stream
+    done = 0
+    for it in range(40):
+        k, s_ = rng.choice([(4, 2), (3, 1)])
+        B = rng.choice([1, 2, 3])
+        if k == 3:
+            Cin, Cout = rng.choice([64, 128]), rng.choice([128, 256])
+        else:
+            Cout = rng.choice([64, 128])
+            Cin = rng.choice([64, 128]) if Cout % 128 else rng.choice([32, 64])
+        H, W = rng.randint(2, 70), rng.randint(2, 70)
+        if k == 4:
+            H, W = 2 * (H // 2 + 1), 2 * (W // 2 + 1)
+        Ho, Wo = (H + 2 - k) // s_ + 1, (W + 2 - k) // s_ + 1
+        nws = query('cy_conv_wgrad_bf16_bn_ws_floats', B, Ho, Wo, Cin, Cout, k, s_)
+        if Ho < 1 or Wo < 1 or nws < 0:
+            continue
+        g = torch.Generator().manual_seed(it)
+        x = torch.randn(B, H, W, Cin, generator=g).to(BF).to(dev())
+        d = torch.randn(B, Ho, Wo, Cout, generator=g).to(BF).to(dev())
+        z = torch.randn(B, Ho, Wo, Cout, generator=g).to(BF).to(dev())
+        g1, g2 = ops.conv_wgrad_bf16(x, d, k, s_, 1), ops.conv_wgrad_bf16(x, d, k, s_, 1)
+        w0 = torch.zeros(Cout, Cin, k, k, dtype=torch.float64, device=dev(), requires_grad=True)
+        F.conv2d(x.double().permute(0, 3, 1, 2), w0, None, stride=s_, padding=1).backward(d.double().permute(0, 3, 1, 2))
+        err = float((g1.double() - w0.grad).abs().max() / w0.grad.abs().max().clamp(min=1e-30))
+        assert err < 2e-5 and torch.equal(g1, g2), (k, s_, B, H, W, Cin, Cout, err)
+        sc = (torch.rand(Cout, generator=g) + 0.5).to(dev()); sh = torch.zeros(Cout, device=dev())
+        mu = (torch.randn(Cout, generator=g) * 0.2).to(dev()); isd = (torch.rand(Cout, generator=g) + 0.5).to(dev())
+        P = B * Ho * Wo
+        red = (torch.randn(Cout, 2, generator=g, dtype=torch.float64) * P * 0.01).to(dev())
+        dz0 = torch.empty_like(z); dg = torch.empty(Cout, device=dev()); db = torch.empty(Cout, device=dev())
+        call('cy_bn_bwd_apply_bf16', z.data_ptr(), d.data_ptr(), 0, dz0.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), isd.data_ptr(), 1.0,
+             red.data_ptr(), dg.data_ptr(), db.data_ptr(), P, Cout, st)
+        dW0 = ops.conv_wgrad_bf16(x, dz0, k, s_, 1)
+        dz1 = torch.full_like(z, float('nan')); dW1 = torch.empty(Cout, Cin, k, k, device=dev()); ws = torch.empty(nws, device=dev())
+        call('cy_conv_wgrad_bf16_bn', x.data_ptr(), d.data_ptr(), z.data_ptr(), dz1.data_ptr(), dW1.data_ptr(), ws.data_ptr(), sc.data_ptr(),
+             mu.data_ptr(), isd.data_ptr(), red.data_ptr(), None, None, B, H, W, Cin, Ho, Wo, Cout, k, s_, st)
+        assert torch.equal(dz1.view(torch.int16), dz0.view(torch.int16)) and torch.equal(dW1, dW0), (k, s_, B, H, W, Cin, Cout)
+        done += 1
+    assert done >= 25
+
+
 def _oracle_bf16_forward(net, x, g):
     """The oracle's DarkCapsuleNet forward with the bf16 path's roundings restated on the CPU: block 1 with bf16 operands of its
     convolution, fp32 statistics and its activation rounded to bf16; blocks 2..5 with bf16 weights, fp32 accumulation, BatchNorm statistics from the fp32
