@@ -1175,6 +1175,8 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     body(S0{}, cid);
     if (cid + 1 < c_hi) body(S1{}, cid + 1);
   }
+  // (the loop's shape is fragile: with `else break;` behind the second body, or written with two breaks, hipcc spills 500 .. 840 bytes per
+  // lane INCLUDING asm load destinations right behind their loads -- tools/check_vmcnt.py holds the kernel to zero scratch)
   // phantom loads may still be in flight and hipcc does not know: their registers must not be reused before they have landed
   wait_set(S0{}, N0{});
   if constexpr (NSET == 2) wait_set(S1{}, N0{});
