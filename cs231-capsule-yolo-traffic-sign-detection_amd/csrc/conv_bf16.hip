@@ -865,9 +865,10 @@ extern "C" int cy_bn_bwd_apply_bf16(const void* Z, const void* dA, int da_f32, v
 // block per 16 lanes, delivered channel-major); nothing is transposed in memory or in registers.
 //  * Block = CO_T output channels x CI_T input channels x ALL taps, 4 waves, each 32 output channels x CI_W input
 //    channels (CI_W = 64 for 3x3, 32 for 4x4): 9 x 2 or 16 x 1 accumulator tiles of 32x32 stay in registers.
-//  * Work unit = 32 consecutive output pixels of one output row: their dZ rows (32 x CO_T) and the KH input rows they
+//  * Work unit (chunk) = 2 output rows x 32 pixels: their dZ rows (64 x CO_T) and the KH + stride input rows they
 //    touch ((31 s + KH) x CI_T each, zero outside the image) are staged in LDS once and serve every tap; rows are
-//    padded so that the four pixel rows of a transposing read fall on different bank groups.
+//    padded so that the four pixel rows of a transposing read fall on different bank groups.  The staging loads are
+//    inline-asm buffer loads through per-image descriptors, two chunks ahead, waited for by hand (see the kernel).
 //  * The pixel range is split over blocks; partial sums go to a slab per split and are added in a fixed order.
 namespace {
 
