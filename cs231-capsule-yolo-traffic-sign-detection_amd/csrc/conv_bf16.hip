@@ -704,6 +704,20 @@ __global__ __launch_bounds__(256) void affine_act_bf16_kernel(const u16* __restr
   float sc[8], sh[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) { sc[k] = scale[c + k]; sh[k] = shift[c + k]; }
+  // four items (64 bytes) in flight per thread: with one, a CU had 32 KB outstanding against the ~72 KB that cover an HBM round trip
+  for (; i + 3 * stride < n8; i += 4 * stride) {
+    u32x4_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = ((const u32x4_t*)Z)[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      float z[8];
+      unpack8(v[u], z);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { const float y = z[k] * sc[k] + sh[k]; z[k] = y > 0.f ? y : y * slope; }
+      store8<OUT_F32>(A, i + u * stride, z);
+    }
+  }
   for (; i < n8; i += stride) {
     float z[8];
     unpack8(((const u32x4_t*)Z)[i], z);
@@ -903,8 +917,11 @@ __device__ __forceinline__ void wg_load(u32x4_t& dst, wg_i32x4 desc, unsigned vo
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(desc), "s"(soff));
 }
 
+// (the s_nop: a vector-memory store of more than 64 bits reads its data registers a cycle behind its issue, and a vector instruction
+// that overwrites them right away needs a wait state in between -- hipcc pads it for its own stores and cannot for an asm statement:
+// without it the first dword of now and then a stored piece was the NEXT item's LDS address, computed into the same register)
 __device__ __forceinline__ void wg_store(const u32x4_t& src, wg_i32x4 desc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" : : "v"(src), "v"(voff), "s"(desc), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(src), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
 
 __device__ __forceinline__ bf16x8 tr_frag(const u16* p0, const u16* p1) {
@@ -1027,7 +1044,9 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
       wg_load(rdz[S][i], dzd, bad ? 0x80000000u : dzv[i], zso);
       if constexpr (BNF) {
         const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(zlds + (S * NDZ + i) * NTHR * 16) + wave * 1024);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" : : "v"(bad ? 0x80000000u : dzv[i]), "s"(zzd), "s"(m0v), "s"(zso) : "memory");
+        unsigned keep;                              // (M0 is compiler-reserved: saved and restored inside the statement that uses it)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(bad ? 0x80000000u : dzv[i]), "s"(zzd), "s"(m0v), "s"(zso) : "memory");
       }
       if constexpr (BNF) dzbad[S] = (dzbad[S] & ~(1u << i)) | ((bad ? 1u : 0u) << i);
     }
@@ -1094,8 +1113,10 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
   using N0 = std::integral_constant<int, 0>;
   load_chunk(S0{});
   wait_set(S0{}, N0{});
+  if constexpr (BNF) asm volatile("s_barrier" ::: "memory");           // (its z came by LDS-DMA: wait, barrier, then read)
   store_chunk(S0{}, 0);
   if constexpr (NSET == 2) load_chunk(S0{});        // chunk c_lo + 1 (or a phantom) waits in set 0
+  if constexpr (BNF && NSET == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX) : "memory");   // its z DMAs: retired in front of the barrier
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // (not __syncthreads(): its fence would wait for the loads in flight)
   // chunk cid lies in LDS buffer P = (cid - c_lo) & 1; set P holds chunk cid + 1, set 1 - P receives chunk cid + 2
   auto body = [&](auto par_c, long long cid) {
@@ -1169,7 +1190,14 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     // set P (requested an iteration ago): only this iteration's NL loads are younger (one set: the loads of this iteration)
     using SetC = std::integral_constant<int, NSET == 2 ? P : 0>;
     wait_set(SetC{}, std::integral_constant<int, NSET == 2 ? NL : 0>{});
+    // BNF: LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt wait FOLLOWED BY A BARRIER (the same lane reading its
+    // own piece right behind the wait returned stale dwords now and then -- invisible while the stale bytes were a previous launch's
+    // identical values).  One set: a barrier of its own behind the wait above.  Two sets: the z DMAs of the chunk requested at the top of
+    // THIS iteration are retired in front of this iteration's end barrier (the NX loads and NDZ stores behind them stay in flight) and
+    // read an iteration later.
+    if constexpr (BNF && NSET == 1) asm volatile("s_barrier" ::: "memory");
     if (cid + 1 < c_hi) store_chunk(SetC{}, 1 - P);
+    if constexpr (BNF && NSET == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NX + NDZ) : "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   };
   for (long long cid = c_lo; cid < c_hi; cid += 2) {

@@ -282,7 +282,16 @@ def test_weight_gradient_with_the_batchnorm_backward_on_the_way_in(case):
         dW1 = torch.empty(Cout, Cin, k, k, device=dev()); ws = torch.empty(nws, device=dev())
         call('cy_conv_wgrad_bf16_bn', x.data_ptr(), d.data_ptr(), z.data_ptr(), dz1.data_ptr(), dW1.data_ptr(), ws.data_ptr(), sc.data_ptr(),
              mu.data_ptr(), isd.data_ptr(), red.data_ptr(), dg1.data_ptr(), db1.data_ptr(), B, H, W, Cin, Ho, Wo, Cout, k, s_, st)
-        assert torch.equal(dz1.view(torch.int16), dz0.view(torch.int16)), rep
+        ne = dz1.view(torch.int16) != dz0.view(torch.int16)
+        if bool(ne.any()):
+            m1 = (red[:, 0] / P).float(); m2 = (red[:, 1] / P).float()
+            ka, kb, kc = sc, -sc * isd * m2, sc * (mu * isd * m2 - m1)
+            want = (d.float() * ka + (z.float() * kb + kc)).to(BF)
+            ix = tuple(ne.nonzero()[0].tolist())
+            info = (rep, int(ne.sum()), ne.nonzero()[:4].tolist(), 'fused', float(dz1[ix]), 'apply', float(dz0[ix]), 'torch', float(want[ix]),
+                    'fused==torch', int((dz1.view(torch.int16) != want.view(torch.int16)).sum()), 'apply==torch', int((dz0.view(torch.int16) != want.view(torch.int16)).sum()))
+            print('WGBN', info)       # (pytest truncates the tuple in the assertion message)
+            assert False, info[:3]
         assert torch.equal(dW1, dW0), (rep, float((dW1 - dW0).abs().max()))
         assert torch.equal(dg1, dg0) and torch.equal(db1, db0)
 
