@@ -22,7 +22,8 @@ LABELS = {('conv_bf16_kernel<256, 256, 2, 4, false, false, false>', 1): 'conv_2 
           ('conv_bf16_kernel<256, 256, 2, 4, false, false, false>', 3): 'conv_3 input gradient, 4 classes in one launch',
           ('conv_bf16_kernel<256, 256, 2, 4, false, true, false>', 1): 'conv_3 input gradient, 4 classes in one launch, with the BatchNorm sums',
           ('conv_bf16_kernel<512, 128, 4, 2, true, false, true>', 1): 'conv_2 input gradient (fp32 output)',
-          ('wgrad_bf16_kernel<3, 1, 4, 8, 1, false>', 1): 'conv_2 weight gradient'}
+          ('wgrad_bf16_kernel<3, 1, 4, 8, 1, false>', 1): 'conv_2 weight gradient',
+          ('wgrad_bf16_kernel<3, 1, 4, 8, 1, true>', 1): 'conv_2 weight gradient with the BatchNorm-backward apply on the way in'}
 out = {'head': sys.argv[5] if len(sys.argv) > 5 else None,
        'method': 'rocprofv3 --kernel-trace --pmc (four separate passes) of tools/run_kernels.py bf16 32 1 (608 x 608, batch 32); the second '
                  'launch of each operation; bytes = 2 x FETCH_SIZE + WRITE_SIZE; mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES); '

@@ -132,7 +132,17 @@ if what == 'bf16':
     timeit('bf16 conv2 fwd (+stats)', lambda: ops.conv_forward_bf16(x, w, b, 3, 1, 1, stats), fl)
     timeit('bf16 conv2 dgrad (fp32 out)', lambda: ops.conv_dgrad_bf16(dz, w, (B, H, H, 128), 3, 1, 1, True), fl)
     timeit('bf16 conv2 wgrad', lambda: ops.conv_wgrad_bf16(x, dz, 3, 1, 1), fl)
-    del x
+    # ... and with the BatchNorm-backward apply on the way in (cy_conv_wgrad_bf16_bn: what the training step launches for blocks 2-4)
+    from capsyolo_amd._lib import call, query
+    nws = query('cy_conv_wgrad_bf16_bn_ws_floats', B, H, H, 128, 256, 3, 1)
+    wsb = torch.empty(nws, device=dev); dzo = torch.empty_like(dz); dWb = torch.empty(256, 128, 3, 3, device=dev)
+    scb, mub, isb = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1, torch.rand(256, device=dev) + 0.5
+    redb = torch.randn(256, 2, dtype=torch.float64, device=dev)
+    zb = torch.randn(B, H, H, 256, device=dev).to(BF)
+    timeit('bf16 conv2 wgrad + bn apply', lambda: call('cy_conv_wgrad_bf16_bn', x.data_ptr(), dz.data_ptr(), zb.data_ptr(), dzo.data_ptr(), dWb.data_ptr(),
+                                                        wsb.data_ptr(), scb.data_ptr(), mub.data_ptr(), isb.data_ptr(), redb.data_ptr(), None, None,
+                                                        B, H, H, 128, H, H, 256, 3, 1, torch.cuda.current_stream().cuda_stream), fl)
+    del x, zb, dzo, wsb
     w3 = torch.randn(64, 256, 4, 4, device=dev) * 0.03
     dz3 = torch.randn(B, H // 2, H // 2, 64, device=dev).to(BF)
     z2 = dz                                       # (any bf16 tensor of conv_2's output shape plays z)
