@@ -904,6 +904,9 @@ struct WgArgs {
 #ifndef CY_WG_DBG
 #define CY_WG_DBG 0
 #endif
+#ifndef CY_WG_ST_AUX
+#define CY_WG_ST_AUX ""              // cache policy of the fused variant's dz store (" nt": swept)
+#endif
 #ifndef CY_WG_RING
 #define CY_WG_RING 3               // B fragments in flight ahead of their MFMAs (swept 2 / 3 / 4)
 #endif
@@ -921,7 +924,7 @@ __device__ __forceinline__ void wg_load(u32x4_t& dst, wg_i32x4 desc, unsigned vo
 // that overwrites them right away needs a wait state in between -- hipcc pads it for its own stores and cannot for an asm statement:
 // without it the first dword of now and then a stored piece was the NEXT item's LDS address, computed into the same register)
 __device__ __forceinline__ void wg_store(const u32x4_t& src, wg_i32x4 desc, unsigned voff, unsigned soff) {
-  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" : : "v"(src), "v"(voff), "s"(desc), "s"(soff) : "memory");
+  asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" CY_WG_ST_AUX "\n\ts_nop 1" : : "v"(src), "v"(voff), "s"(desc), "s"(soff) : "memory");
 }
 
 __device__ __forceinline__ bf16x8 tr_frag(const u16* p0, const u16* p1) {
