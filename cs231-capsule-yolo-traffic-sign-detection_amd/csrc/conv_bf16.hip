@@ -900,7 +900,8 @@ struct WgArgs {
   const u16* Z; u16* dZout; const float* bnc;
 };
 
-// developer knob for timing experiments (results are wrong when set): 1 one MFMA per chunk, 2 every load out of range (no memory traffic)
+// developer knob for timing experiments (results are wrong when set): 1 one MFMA per chunk, 2 every load out of range (no memory traffic),
+// fused variant: 4 no z DMA, 8 dz stores dropped, 16 no BatchNorm arithmetic
 #ifndef CY_WG_DBG
 #define CY_WG_DBG 0
 #endif
@@ -1045,7 +1046,7 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
     for (int i = 0; i < NDZ; ++i) {
       const bool bad = (CY_WG_DBG & 2) || (dzpx[i] & 255) >= zlim || (dzpx[i] >> 8) >= zrlim;
       wg_load(rdz[S][i], dzd, bad ? 0x80000000u : dzv[i], zso);
-      if constexpr (BNF) {
+      if constexpr (BNF && !(CY_WG_DBG & 4)) {
         const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(zlds + (S * NDZ + i) * NTHR * 16) + wave * 1024);
         unsigned keep;                              // (M0 is compiler-reserved: saved and restored inside the statement that uses it)
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -1083,11 +1084,11 @@ __global__ __launch_bounds__(64 * NW, 1) void wgrad_bf16_kernel(WgArgs a) {
         unpack8(*(const u32x4_t*)(zlds + ((S * NDZ + i) * NTHR + t) * 16), z);
         const float* kc = bncs + q * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) o[k] = __builtin_fmaf(d[k], kc[k], __builtin_fmaf(z[k], kc[CO_T + k], kc[2 * CO_T + k]));
+        for (int k = 0; k < 8; ++k) o[k] = (CY_WG_DBG & 16) ? d[k] + z[k] : __builtin_fmaf(d[k], kc[k], __builtin_fmaf(z[k], kc[CO_T + k], kc[2 * CO_T + k]));
         u32x4_t ov = pack8(o);
         if ((dzbad[S] >> i) & 1u) ov = u32x4_t{0u, 0u, 0u, 0u};       // outside the image: no pixel, no contribution
         if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = ov;
-        wg_store(ov, ozd[S], ((dzbad[S] >> i) & 1u) ? 0x80000000u : dzv[i], ozs[S]);
+        wg_store(ov, ozd[S], ((CY_WG_DBG & 8) || ((dzbad[S] >> i) & 1u)) ? 0x80000000u : dzv[i], ozs[S]);
       } else {
         if (c < DZ_CH) *(u32x4_t*)(dzimg + buf * DZ_IMG + px * DZB + q * 16) = rdz[S][i];
       }
